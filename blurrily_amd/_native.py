@@ -1,0 +1,80 @@
+"""ctypes binding of libblurrily_hip.so (include/blurrily_storage.h).
+
+Fails loudly when the library is missing: there is no pure-Python or CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblurrily_hip.so")
+
+
+class TrigramMatch(C.Structure):
+    """storage.h:18-24 -- packed 12-byte row."""
+    _pack_ = 1
+    _fields_ = [("reference", C.c_uint32), ("matches", C.c_uint32), ("weight", C.c_uint32)]
+
+
+class TrigramStat(C.Structure):
+    """storage.h:26-30."""
+    _fields_ = [("references", C.c_uint32), ("trigrams", C.c_uint32)]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [
+        ("device_ordinal", C.c_int32), ("n_refs", C.c_uint32), ("n_windows", C.c_uint32),
+        ("window_bits", C.c_uint32), ("n_entries", C.c_uint64), ("device_bytes", C.c_uint64),
+        ("last_find_kernel_ms", C.c_double), ("last_tokenise_kernel_ms", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  blurrily_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH, use_errno=True)
+    vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+    sig = {
+        "blurrily_storage_new": (C.c_int, [vpp]),
+        "blurrily_storage_load": (C.c_int, [vpp, C.c_char_p]),
+        "blurrily_storage_close": (C.c_int, [vpp]),
+        "blurrily_storage_mark": (None, [vp]),
+        "blurrily_storage_save": (C.c_int, [vp, C.c_char_p]),
+        "blurrily_storage_put": (C.c_int, [vp, C.c_char_p, C.c_uint32, C.c_uint32]),
+        "blurrily_storage_delete": (C.c_int, [vp, C.c_uint32]),
+        "blurrily_storage_find": (C.c_int, [vp, C.c_char_p, C.c_uint16, C.c_void_p]),
+        "blurrily_storage_stats": (C.c_int, [vp, C.POINTER(TrigramStat)]),
+        "blurrily_storage_put_many": (C.c_long, [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+        "blurrily_storage_find_batch": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint16,
+                                                  C.c_void_p, C.c_void_p]),
+        "blurrily_storage_find_batch_device": (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                         C.c_uint16, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p]),
+        "blurrily_storage_sync_device": (C.c_int, [vp]),
+        "blurrily_tokeniser_parse_string": (C.c_int, [C.c_char_p, C.c_void_p]),
+        "blurrily_storage_device_info": (C.c_int, [vp, C.POINTER(DeviceInfo)]),
+        "blurrily_storage_set_timing": (None, [vp, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "blurrily_storage_new", "blurrily_storage_load", "blurrily_storage_close", "blurrily_storage_mark",
+    "blurrily_storage_save", "blurrily_storage_put", "blurrily_storage_delete", "blurrily_storage_find",
+    "blurrily_storage_stats", "blurrily_storage_put_many", "blurrily_storage_find_batch",
+    "blurrily_storage_find_batch_device", "blurrily_storage_sync_device", "blurrily_tokeniser_parse_string",
+    "blurrily_storage_device_info", "blurrily_storage_set_timing",
+)

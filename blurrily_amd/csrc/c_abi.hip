@@ -1,0 +1,325 @@
+// c_abi.hip -- extern "C" entry points of libblurrily_hip.so
+// (include/blurrily_storage.h).  Part 1 mirrors ext/blurrily/storage.h:36-117.
+#include "../../include/blurrily_storage.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "device_index.h"
+#include "find_kernels.h"
+#include "host_index.h"
+
+using namespace blurrily;
+
+namespace {
+
+#define BLURRILY_HIP_TRY(expr)                                                        \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      std::fprintf(stderr, "blurrily_hip: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+      errno = (e_ == hipErrorOutOfMemory) ? ENOMEM : EIO;                             \
+      return -1;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+// Device scratch that lives as long as the map and only ever grows.
+struct DeviceBuffer {
+  void*  p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t want, hipStream_t stream) {
+    if (want <= bytes) return 0;
+    if (p) { (void)hipStreamSynchronize(stream); (void)hipFree(p); p = nullptr; bytes = 0; }
+    const size_t grow = std::max(want, bytes + bytes / 2);
+    BLURRILY_HIP_TRY(hipMalloc(&p, grow));
+    bytes = grow;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct trigram_map_t {
+  HostIndex*  host = nullptr;
+  DeviceIndex dev;
+  int         n_cus = 0;
+  bool        timing = false;
+  double      last_find_ms = 0.0, last_tok_ms = 0.0;
+  hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  DeviceBuffer ws_codes, ws_small, ws_io_packed, ws_io_offsets, ws_io_results, ws_io_counts;
+};
+
+namespace {
+
+int ensure_device(trigram_map m) {
+  if (m->dev.device >= 0 && m->dev.built_from == m->host->generation()) return 0;
+  if (device_index_build(*m->host, &m->dev) < 0) return -1;
+  if (m->n_cus == 0) {
+    hipDeviceProp_t prop;
+    BLURRILY_HIP_TRY(hipGetDeviceProperties(&prop, m->dev.device));
+    m->n_cus = prop.multiProcessorCount;
+  }
+  return 0;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Enqueue tokenise + find for n device-resident needles.
+int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
+             uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long,
+             hipStream_t stream) {
+  if (n == 0) return 0;
+  if (n > 0xFFFFFFF0ull) { errno = EINVAL; return -1; }
+  const DeviceIndex& ix = m->dev;
+
+  // scratch: codes | per-needle arrays | scalars
+  const size_t code_slots = packed_bytes + n;
+  if (m->ws_codes.reserve(align_up(code_slots * sizeof(uint16_t), 256), stream) < 0) return -1;
+  const size_t per_n = align_up(n * sizeof(uint32_t), 256);
+  const bool multi_pass = limit > 256;             // long needles keep 256 rows per pass, short ones 1024
+  const size_t small_bytes = per_n * 3 + (multi_pass ? align_up(n * 8, 256) + per_n : 0) + 256;
+  if (m->ws_small.reserve(small_bytes, stream) < 0) return -1;
+  unsigned char* sp = static_cast<unsigned char*>(m->ws_small.p);
+  uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1..]=queues
+  uint32_t* q_ntri   = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
+  uint32_t* q_nb_ws  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
+  uint32_t* big_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
+  unsigned long long* floor_hi = nullptr; uint32_t* floor_rk = nullptr;
+  if (multi_pass) {
+    floor_hi = reinterpret_cast<unsigned long long*>(sp);          sp += align_up(n * 8, 256);
+    floor_rk = reinterpret_cast<uint32_t*>(sp);
+  }
+  uint32_t* q_nb = d_nb ? d_nb : q_nb_ws;
+  BLURRILY_HIP_TRY(hipMemsetAsync(scalars, 0, 256, stream));
+
+  if (m->timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev[0], stream));
+  TokeniseArgs t{d_packed, d_offsets, uint32_t(n), ix.d_code_total, static_cast<uint16_t*>(m->ws_codes.p),
+                 q_ntri, q_nb, big_list, scalars};
+  if (launch_tokenise(t, stream) < 0) return -1;
+  if (m->timing) {
+    BLURRILY_HIP_TRY(hipEventRecord(m->ev[1], stream));
+    BLURRILY_HIP_TRY(hipEventRecord(m->ev[2], stream));
+  }
+
+  FindArgs a{};
+  a.slice_off = ix.d_slice_off; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
+  a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
+  a.offsets = d_offsets; a.qcodes = static_cast<const uint16_t*>(m->ws_codes.p);
+  a.q_ntri = q_ntri; a.q_nb = q_nb; a.results = d_results; a.counts = d_counts; a.limit = limit;
+  a.floor_hi = floor_hi; a.floor_rk = floor_rk;
+  // every launch gets its own zeroed queue word (scalars[1..63]); recycled in stream order
+  uint32_t queue_slot = 1;
+  auto next_queue = [&]() -> uint32_t* {
+    if (queue_slot >= 64) {
+      if (hipMemsetAsync(scalars + 1, 0, 252, stream) != hipSuccess) return nullptr;
+      queue_slot = 1;
+    }
+    return scalars + queue_slot++;
+  };
+
+  if (limit == 0) {
+    BLURRILY_HIP_TRY(hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), stream));
+  } else {
+    // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
+    for (uint32_t base = 0; base < limit; base += 1024) {
+      a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
+      a.pass_base = base; a.keep = std::min<uint32_t>(1024, limit - base);
+      a.pool_cap = find_pool_cap(a.keep);
+      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+      const uint32_t grid = uint32_t(std::min<size_t>(n, size_t(m->n_cus) * 2));
+      if (launch_find(a, false, grid, stream) < 0) return -1;
+    }
+    // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
+    if (maybe_long) {
+      for (uint32_t base = 0; base < limit; base += 256) {
+        a.work_list = big_list; a.n_work_dev = scalars; a.n_work = 0;
+        a.pass_base = base; a.keep = std::min<uint32_t>(256, limit - base);
+        a.pool_cap = 1024;
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        const uint32_t grid = uint32_t(std::min<size_t>(n, size_t(m->n_cus)));
+        if (launch_find(a, true, grid, stream) < 0) return -1;
+      }
+    }
+  }
+  if (m->timing) {
+    BLURRILY_HIP_TRY(hipEventRecord(m->ev[3], stream));
+    BLURRILY_HIP_TRY(hipEventSynchronize(m->ev[3]));
+    float ms = 0.f;
+    BLURRILY_HIP_TRY(hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->last_tok_ms = ms;
+    BLURRILY_HIP_TRY(hipEventElapsedTime(&ms, m->ev[2], m->ev[3])); m->last_find_ms = ms;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blurrily_storage_new(trigram_map* haystack) {
+  trigram_map m = new (std::nothrow) trigram_map_t();
+  if (!m) { errno = ENOMEM; return -1; }
+  m->host = new (std::nothrow) HostIndex();
+  if (!m->host) { delete m; errno = ENOMEM; return -1; }
+  *haystack = m;
+  return 0;
+}
+
+int blurrily_storage_load(trigram_map* haystack, const char* path) {
+  HostIndex* ix = HostIndex::load(path);
+  if (!ix) return -1;                                   // errno set by load()
+  trigram_map m = new (std::nothrow) trigram_map_t();
+  if (!m) { delete ix; errno = ENOMEM; return -1; }
+  m->host = ix;
+  *haystack = m;
+  return 0;
+}
+
+int blurrily_storage_close(trigram_map* haystack) {
+  trigram_map m = *haystack;
+  if (m) {
+    if (m->dev.device >= 0) {
+      (void)hipDeviceSynchronize();
+      device_index_free(&m->dev);
+    }
+    for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+    m->ws_codes.release(); m->ws_small.release(); m->ws_io_packed.release();
+    m->ws_io_offsets.release(); m->ws_io_results.release(); m->ws_io_counts.release();
+    delete m->host;
+    delete m;
+  }
+  *haystack = nullptr;
+  return 0;
+}
+
+void blurrily_storage_mark(trigram_map) {}
+
+int blurrily_storage_save(trigram_map haystack, const char* path) { return haystack->host->save(path); }
+
+int blurrily_storage_put(trigram_map haystack, const char* needle, uint32_t reference, uint32_t weight) {
+  return haystack->host->put(needle, std::strlen(needle), reference, weight);
+}
+
+long blurrily_storage_put_many(trigram_map haystack, const char* packed, const uint64_t* offsets,
+                               const uint32_t* references, const uint32_t* weights, size_t n) {
+  long total = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const char* s = packed + offsets[i];
+    const size_t cap = size_t(offsets[i + 1] - offsets[i]);
+    const void* nul = std::memchr(s, 0, cap);
+    const size_t len = nul ? size_t(static_cast<const char*>(nul) - s) : cap;
+    total += haystack->host->put(s, len, references[i], weights ? weights[i] : 0u);
+  }
+  return total;
+}
+
+int blurrily_storage_delete(trigram_map haystack, uint32_t reference) { return haystack->host->del(reference); }
+
+int blurrily_storage_stats(trigram_map haystack, trigram_stat_t* stats) {
+  stats->references = haystack->host->total_refs();
+  stats->trigrams   = haystack->host->total_trigrams();
+  return 0;
+}
+
+int blurrily_storage_sync_device(trigram_map haystack) {
+  haystack->host->sort_dirty_buckets();
+  return ensure_device(haystack);
+}
+
+int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size_t packed_bytes,
+                                       const uint64_t* d_offsets, size_t n, uint16_t limit,
+                                       trigram_match d_results, uint32_t* d_counts,
+                                       uint32_t* d_nb_entries, void* stream) {
+  // The needles are not visible to the host here, so every dirty bucket is
+  // sorted (the reference sorts only the needle's own, storage.c:516; results
+  // are identical, see DESIGN.md "Mutation and device sync").
+  if (m->host->dirty_buckets()) m->host->sort_dirty_buckets();
+  if (ensure_device(m) < 0) return -1;
+  if (m->timing && !m->ev[0])
+    for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
+  return run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_results, d_counts, d_nb_entries, true,
+                  static_cast<hipStream_t>(stream));
+}
+
+int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_t* offsets, size_t n,
+                                uint16_t limit, trigram_match results, uint32_t* counts) {
+  if (n == 0) return 0;
+  // what the reference's find does first: tokenise, sort the needle's dirty buckets
+  size_t max_len = 0;
+  const bool any_dirty = m->host->dirty_buckets() != 0;
+  std::vector<uint16_t> codes;
+  for (size_t i = 0; i < n; ++i) {
+    const char* s = packed + offsets[i];
+    const size_t cap = size_t(offsets[i + 1] - offsets[i]);
+    const void* nul = std::memchr(s, 0, cap);
+    const size_t len = nul ? size_t(static_cast<const char*>(nul) - s) : cap;
+    max_len = std::max(max_len, len);
+    if (any_dirty) {
+      codes.resize(len + 1);
+      const int nt = tokenise(s, len, codes.data());
+      for (int k = 0; k < nt; ++k) m->host->sort_bucket_if_dirty(codes[k]);
+    }
+  }
+  if (ensure_device(m) < 0) return -1;
+  if (m->timing && !m->ev[0])
+    for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
+
+  hipStream_t stream = nullptr;
+  const size_t packed_bytes = size_t(offsets[n]);
+  if (m->ws_io_packed.reserve(std::max<size_t>(packed_bytes, 16), stream) < 0 ||
+      m->ws_io_offsets.reserve((n + 1) * sizeof(uint64_t), stream) < 0 ||
+      m->ws_io_results.reserve(std::max<size_t>(n * size_t(limit) * sizeof(trigram_match_t), 16), stream) < 0 ||
+      m->ws_io_counts.reserve(n * sizeof(uint32_t), stream) < 0)
+    return -1;
+  if (packed_bytes)
+    BLURRILY_HIP_TRY(hipMemcpyAsync(m->ws_io_packed.p, packed, packed_bytes, hipMemcpyHostToDevice, stream));
+  BLURRILY_HIP_TRY(hipMemcpyAsync(m->ws_io_offsets.p, offsets, (n + 1) * sizeof(uint64_t),
+                                  hipMemcpyHostToDevice, stream));
+  if (run_find(m, static_cast<const char*>(m->ws_io_packed.p), packed_bytes,
+               static_cast<const uint64_t*>(m->ws_io_offsets.p), n, limit,
+               static_cast<trigram_match>(m->ws_io_results.p), static_cast<uint32_t*>(m->ws_io_counts.p),
+               nullptr, max_len > 126, stream) < 0)
+    return -1;
+  BLURRILY_HIP_TRY(hipMemcpyAsync(counts, m->ws_io_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  if (limit)
+    BLURRILY_HIP_TRY(hipMemcpyAsync(results, m->ws_io_results.p, n * size_t(limit) * sizeof(trigram_match_t),
+                                    hipMemcpyDeviceToHost, stream));
+  BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int blurrily_storage_find(trigram_map haystack, const char* needle, uint16_t limit, trigram_match results) {
+  const uint64_t offsets[2] = {0, std::strlen(needle)};
+  uint32_t count = 0;
+  // the device writes `limit` rows per needle; go through a scratch so a short
+  // caller buffer is never over-written beyond `limit` rows (it is exactly limit rows)
+  if (blurrily_storage_find_batch(haystack, needle, offsets, 1, limit, results, &count) < 0) return -1;
+  return int(count);
+}
+
+int blurrily_tokeniser_parse_string(const char* input, uint16_t* output) {
+  return tokenise(input, std::strlen(input), output);
+}
+
+int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
+  info->device_ordinal = m->dev.device;
+  info->n_refs = m->dev.n_refs;
+  info->n_windows = m->dev.n_windows;
+  info->window_bits = kWindowBits;
+  info->n_entries = m->dev.n_entries;
+  info->device_bytes = m->dev.device_bytes;
+  info->last_find_kernel_ms = m->last_find_ms;
+  info->last_tokenise_kernel_ms = m->last_tok_ms;
+  return 0;
+}
+
+void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabled != 0; }
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// device_index.h -- the read-only, HBM-resident form of the trigram index.
+//
+// Layout (see DESIGN.md "Data layout in HBM"):
+//   * references are compacted to ranks 0..N-1 in ascending reference order
+//     (monotone, so "rank ascending" == the reference's tie order "ref
+//     ascending", spec/integration_spec.rb:37-42); ref_of_rank / weight_of_rank
+//     are the side tables (a reference has one weight in every bucket:
+//     storage.c:418 writes the same {reference, weight} into each of them).
+//   * the rank space is cut into windows of 2^window_bits ranks; the postings
+//     are stored window-major: for window w, for trigram code t, the sorted
+//     16-bit in-window ranks of the references whose string contains t.
+//     slice_off[w * kNumCodes + t] is the start of that slice in `ent`
+//     (a CSR over (window, code)); one extra element closes the last slice.
+//   * code_total[t] = used[t] of the reference's bucket t (storage.c:501), for
+//     the matched-entries metric.
+// An entry costs 2 bytes in HBM instead of the reference's 8-byte
+// (reference, weight) pair; the algorithmic byte count of DESIGN.md keeps the
+// reference's 8 bytes.
+#pragma once
+#include <cstdint>
+
+#include "host_index.h"
+
+namespace blurrily {
+
+constexpr uint32_t kWindowBits = 16;
+constexpr uint32_t kWindowSize = 1u << kWindowBits;
+constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byte over-reads)
+
+struct DeviceIndex {
+  int       device        = -1;
+  uint32_t  n_refs        = 0;
+  uint32_t  n_windows     = 0;
+  uint64_t  n_entries     = 0;
+  uint64_t  device_bytes  = 0;
+  uint64_t  built_from    = 0;        // HostIndex::generation() this was built from
+  uint32_t* d_ref_of_rank    = nullptr;   // [n_refs]
+  uint32_t* d_weight_of_rank = nullptr;   // [n_refs]
+  uint32_t* d_slice_off      = nullptr;   // [n_windows * kNumCodes + 1]
+  uint16_t* d_ent            = nullptr;   // [n_entries + kEntPad]
+  uint32_t* d_code_total     = nullptr;   // [kNumCodes]
+};
+
+// Build the device image of `host` on the current HIP device.  Returns 0, or
+// -1 with errno: ENODEV (no device), ENOMEM, EPROTO (postings violate the
+// invariants put() guarantees: duplicate reference inside a bucket, a
+// reference with two different weights, a reference missing from the leading
+// buckets).
+int  device_index_build(const HostIndex& host, DeviceIndex* out);
+void device_index_free(DeviceIndex* ix);
+
+}  // namespace blurrily

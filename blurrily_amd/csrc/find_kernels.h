@@ -1,0 +1,57 @@
+// find_kernels.h -- launch interface of the find hot path (find_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/blurrily_storage.h"
+#include "device_index.h"
+
+namespace blurrily {
+
+struct TokeniseArgs {
+  const char*     packed;      // needle bytes (device)
+  const uint64_t* offsets;     // [n+1] byte offsets (device)
+  uint32_t        n;
+  const uint32_t* code_total;  // [kNumCodes] bucket sizes
+  uint16_t*       qcodes;      // [offsets[n] + n] distinct codes, needle q at offsets[q]+q
+  uint32_t*       q_ntri;      // [n] distinct trigram count per needle
+  uint32_t*       q_nb;        // [n] nb_entries per needle (storage.c:498-502)
+  uint32_t*       big_list;    // [n] needles with > 127 distinct trigrams
+  uint32_t*       big_count;   // [1]
+};
+
+struct FindArgs {
+  // index
+  const uint32_t* slice_off;
+  const uint16_t* ent;
+  const uint32_t* ref_of_rank;
+  const uint32_t* weight_of_rank;
+  uint32_t        n_refs;
+  uint32_t        n_windows;
+  // needles
+  const uint64_t* offsets;
+  const uint16_t* qcodes;
+  const uint32_t* q_ntri;
+  const uint32_t* q_nb;
+  const uint32_t* work_list;   // nullptr: slots are needle ids, long needles skipped
+  const uint32_t* n_work_dev;  // when set, the number of slots is read from the device
+  uint32_t        n_work;
+  uint32_t*       queue;       // [1] zeroed before launch
+  // results
+  trigram_match_t* results;    // [n * limit]
+  uint32_t*       counts;      // [n]
+  uint32_t        limit;       // row stride
+  uint32_t        keep;        // rows wanted from this pass
+  uint32_t        pass_base;   // rows already delivered by earlier passes
+  uint32_t        pool_cap;    // power of two, >= 4*keep
+  unsigned long long* floor_hi;  // [n] last key of the previous pass (multi-pass only)
+  uint32_t*       floor_rk;
+};
+
+uint32_t find_pool_cap(uint32_t keep);
+int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);
+int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
+
+}  // namespace blurrily

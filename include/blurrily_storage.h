@@ -1,0 +1,147 @@
+/*
+ * blurrily_storage.h -- C ABI of libblurrily_hip.so, the MI355X-native drop-in
+ * for the trigram index behind Blurrily::Map (mezis/blurrily v1.0.2).
+ *
+ * Part 1 declares the nine entry points of the reference's
+ * ext/blurrily/storage.h:36-117 with the same names, argument meaning and
+ * error behaviour, so the reference's own Ruby glue (ext/blurrily/map_ext.c)
+ * links against this library unchanged.  Part 2 adds the
+ * batched / device-resident entry points the reference has no counterpart for;
+ * each batched element is defined as exactly one blurrily_storage_find.
+ *
+ * `find` runs on the GPU (hand-written HIP kernels for gfx950).  There is no
+ * CPU fallback: without a usable device every find entry point returns -1 with
+ * errno = ENODEV and says so on stderr.
+ */
+#ifndef BLURRILY_AMD_STORAGE_H
+#define BLURRILY_AMD_STORAGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- types ---- */
+
+struct trigram_map_t;                               /* opaque; storage.h:15-16 */
+typedef struct trigram_map_t* trigram_map;
+
+/* storage.h:18-24 -- packed 12-byte result row. */
+struct __attribute__((__packed__)) trigram_match_t {
+  uint32_t reference;
+  uint32_t matches;
+  uint32_t weight;
+};
+typedef struct trigram_match_t  trigram_match_t;
+typedef struct trigram_match_t* trigram_match;
+
+/* storage.h:26-30 */
+typedef struct trigram_stat_t {
+  uint32_t references;
+  uint32_t trigrams;
+} trigram_stat_t;
+
+/* ------------------------------------------------- part 1: reference ABI ---- */
+
+/* storage.h:36 / storage.c:178-206.  New empty map.  0 on success, <0 + errno. */
+int blurrily_storage_new(trigram_map* haystack);
+
+/* storage.h:41 / storage.c:210-266.  Load a `.trigrams` file written by this
+ * library or by the reference (same bytes).  <0 + errno on failure: ENOENT
+ * etc. from open(2); EPROTO for a short file, bad magic, wrong endianness or
+ * pointer size (storage.c:226-230,245-250) and for out-of-bounds bucket
+ * descriptors. */
+int blurrily_storage_load(trigram_map* haystack, const char* path);
+
+/* storage.h:46 / storage.c:270-295.  Release host and device memory; sets
+ * *haystack = NULL. */
+int blurrily_storage_close(trigram_map* haystack);
+
+/* storage.h:51 / storage.c:625-629.  GC mark hook of the Ruby glue.  The ref
+ * set here is native (no Ruby objects) so this is a no-op. */
+void blurrily_storage_mark(trigram_map haystack);
+
+/* storage.h:58 / storage.c:299-377.  Write the map to `path` atomically
+ * (temp file + rename), byte-identical to what the reference writes for the
+ * same sequence of operations. */
+int blurrily_storage_save(trigram_map haystack, const char* path);
+
+/* storage.h:70 / storage.c:398-473.  Returns the number of trigrams added,
+ * 0 if `reference` is already present.  weight == 0 -> strlen(needle). */
+int blurrily_storage_put(trigram_map haystack, const char* needle,
+                         uint32_t reference, uint32_t weight);
+
+/* storage.h:96 / storage.c:584-612.  Returns the number of entries removed. */
+int blurrily_storage_delete(trigram_map haystack, uint32_t reference);
+
+/* storage.h:110 / storage.c:477-580.  At most `limit` rows into the
+ * caller-allocated `results`, ordered by matches descending, weight ascending,
+ * reference ascending.  Returns the row count, or -1 (errno ENODEV) when no
+ * GPU is usable. */
+int blurrily_storage_find(trigram_map haystack, const char* needle,
+                          uint16_t limit, trigram_match results);
+
+/* storage.h:117 / storage.c:616-621. */
+int blurrily_storage_stats(trigram_map haystack, trigram_stat_t* stats);
+
+/* ------------------------------------------- part 2: batched extensions ---- */
+
+/* Same as `n` calls of blurrily_storage_put, in order (no reference
+ * counterpart; avoids one FFI crossing per string for bulk imports).
+ * Needle i is the bytes packed[offsets[i] .. offsets[i+1]) cut at the first
+ * NUL.  weights may be NULL (all 0).  Returns the total number of trigrams
+ * added, or -1. */
+long blurrily_storage_put_many(trigram_map haystack, const char* packed,
+                               const uint64_t* offsets, const uint32_t* references,
+                               const uint32_t* weights, size_t n);
+
+/* n independent finds on the GPU in one launch sequence.  Host buffers in,
+ * host buffers out.  results holds n*limit rows (query i owns rows
+ * [i*limit, i*limit+counts[i])); counts holds n row counts.  Returns 0, or -1
+ * with errno (ENODEV: no GPU). */
+int blurrily_storage_find_batch(trigram_map haystack, const char* packed,
+                                const uint64_t* offsets, size_t n, uint16_t limit,
+                                trigram_match results, uint32_t* counts);
+
+/* Device-resident variant: every pointer is a device pointer on the map's GPU;
+ * work is enqueued on `stream` (a hipStream_t; NULL = default stream) and NOT
+ * synchronised.  d_nb_entries (optional, may be NULL) receives per query the
+ * reference's nb_entries (storage.c:498-502), the unit of the
+ * matched-entries/s metric. */
+int blurrily_storage_find_batch_device(trigram_map haystack, const char* d_packed,
+                                       size_t packed_bytes, /* == offsets[n] */
+                                       const uint64_t* d_offsets, size_t n, uint16_t limit,
+                                       trigram_match d_results, uint32_t* d_counts,
+                                       uint32_t* d_nb_entries, void* stream);
+
+/* Build / refresh the device-resident index now (it is otherwise built lazily
+ * by the first find after a mutation).  0, or -1 with errno. */
+int blurrily_storage_sync_device(trigram_map haystack);
+
+/* Tokeniser (ext/blurrily/tokeniser.h:34, tokeniser.c:59-119): `output` needs
+ * strlen(input)+1 slots; returns the number of distinct codes, ascending. */
+int blurrily_tokeniser_parse_string(const char* input, uint16_t* output);
+
+/* Introspection for tests / bench (no reference counterpart). */
+typedef struct blurrily_device_info_t {
+  int32_t  device_ordinal;      /* -1 if no usable GPU                           */
+  uint32_t n_refs;              /* distinct references in the device index       */
+  uint32_t n_windows;           /* reference-rank windows                        */
+  uint32_t window_bits;         /* log2(ranks per window)                        */
+  uint64_t n_entries;           /* (trigram, ref) entries resident               */
+  uint64_t device_bytes;        /* HBM bytes held by the index                   */
+  double   last_find_kernel_ms; /* HIP-event time of the last find kernel launch */
+  double   last_tokenise_kernel_ms;
+} blurrily_device_info_t;
+int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* info);
+
+/* When non-zero, find_batch_device brackets its kernels with hipEvents on the
+ * launch stream and synchronises to fill last_*_kernel_ms (bench/profiling). */
+void blurrily_storage_set_timing(trigram_map haystack, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLURRILY_AMD_STORAGE_H */

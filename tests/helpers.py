@@ -1,0 +1,150 @@
+"""Test-side access to the checkers under oracle/ (never imported by the product)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libblurrily_ref.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class Match(C.Structure):
+    _pack_ = 1
+    _fields_ = [("reference", C.c_uint32), ("matches", C.c_uint32), ("weight", C.c_uint32)]
+
+
+def _rows(buf, n):
+    return [[buf[k].reference, buf[k].matches, buf[k].weight] for k in range(n)]
+
+
+class Oracle:
+    """oracle/blurrily_oracle.c -- CPU restatement of the reference algorithm."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = C.CDLL(os.path.join(ORACLE_DIR, "liboracle.so"))
+            L.oracle_new.restype = C.c_void_p
+            L.oracle_free.argtypes = [C.c_void_p]
+            L.oracle_put.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+            L.oracle_delete.argtypes = [C.c_void_p, C.c_uint32]
+            L.oracle_find.argtypes = [C.c_void_p, C.c_char_p, C.c_uint16, C.c_void_p]
+            L.oracle_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+            L.oracle_tokenise.argtypes = [C.c_char_p, C.c_void_p]
+            L.oracle_nb_entries.argtypes = [C.c_void_p, C.c_char_p]
+            L.oracle_nb_entries.restype = C.c_uint64
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self):
+        self.L = self.lib()
+        self.h = self.L.oracle_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_free(self.h)
+            self.h = None
+
+    def put(self, needle, ref, weight=0):
+        return self.L.oracle_put(self.h, needle, ref, weight)
+
+    def delete(self, ref):
+        return self.L.oracle_delete(self.h, ref)
+
+    def find(self, needle, limit=10):
+        buf = (Match * max(limit, 1))()
+        n = self.L.oracle_find(self.h, needle, limit, buf)
+        return _rows(buf, n)
+
+    def stats(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self.L.oracle_stats(self.h, C.byref(a), C.byref(b))
+        return {"references": a.value, "trigrams": b.value}
+
+    def nb_entries(self, needle):
+        return int(self.L.oracle_nb_entries(self.h, needle))
+
+    @classmethod
+    def tokenise(cls, needle):
+        out = (C.c_uint16 * (len(needle) + 1))()
+        n = cls.lib().oracle_tokenise(needle, out)
+        return list(out[:n])
+
+
+class Reference:
+    """The reference's own C compiled in place (oracle/_ref), bound lazily via ref_shim."""
+
+    _shim = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(REF_SO) and os.path.exists(os.path.join(ORACLE_DIR, "libref_shim.so"))
+
+    @classmethod
+    def shim(cls):
+        if cls._shim is None:
+            S = C.CDLL(os.path.join(ORACLE_DIR, "libref_shim.so"))
+            assert S.ref_open(REF_SO.encode()) == 0
+            S.ref_find.argtypes = [C.c_void_p, C.c_char_p, C.c_uint16, C.c_void_p]
+            S.ref_save.argtypes = [C.c_void_p, C.c_char_p]
+            S.ref_stats.argtypes = [C.c_void_p, C.c_void_p]
+            S.ref_tokenise.argtypes = [C.c_char_p, C.c_void_p]
+            S.ref_find_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint16, C.c_void_p]
+            S.ref_find_many.restype = C.c_long
+            cls._shim = S
+        return cls._shim
+
+    def __init__(self, path):
+        """Load a .trigrams file with the reference's blurrily_storage_load."""
+        self.S = self.shim()
+        self.h = C.c_void_p()
+        res = self.S.ref_load(C.byref(self.h), os.fsencode(path))
+        if res < 0:
+            raise OSError(C.get_errno(), "reference load failed")
+
+    def close(self):
+        if self.h:
+            self.S.ref_close(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def find(self, needle, limit=10):
+        buf = (Match * max(limit, 1))()
+        n = self.S.ref_find(self.h, needle, limit, buf)
+        return _rows(buf, n)
+
+    def save(self, path):
+        return self.S.ref_save(self.h, os.fsencode(path))
+
+    def stats(self):
+        st = (C.c_uint32 * 2)()
+        self.S.ref_stats(self.h, st)
+        return {"references": st[0], "trigrams": st[1]}
+
+    @classmethod
+    def tokenise(cls, needle):
+        out = (C.c_uint16 * (len(needle) + 1))()
+        n = cls.shim().ref_tokenise(needle, out)
+        return list(out[:n])
+
+
+def build_pair(strings, refs=None, weights=None):
+    """The same haystack in the product (RawMap) and in the oracle."""
+    from blurrily_amd import RawMap
+    m, o = RawMap(), Oracle()
+    refs = list(range(1, len(strings) + 1)) if refs is None else refs
+    weights = [0] * len(strings) if weights is None else weights
+    for s, r, w in zip(strings, refs, weights):
+        a = m.put(s, r, w)
+        b = o.put(s, r, w)
+        assert a == b, (s, r, w, a, b)
+    return m, o

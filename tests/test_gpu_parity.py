@@ -1,0 +1,169 @@
+"""GPU parity: the HIP find path (through the C ABI) against the oracle, bit-exact.
+
+Reads like spec/blurrily/map_spec.rb '#find' (:118-210) plus seeded random haystacks.
+"""
+import numpy as np
+import pytest
+
+import workloads as W
+from blurrily_amd import Map, RawMap
+from helpers import Oracle, build_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_present():
+    m = Map()
+    m.put("london", 1)
+    m.sync_device()
+    assert m.device_info()["device_ordinal"] >= 0
+
+
+# ---- spec/blurrily/map_spec.rb:118-210 -------------------------------------------------
+
+def test_empty_map_returns_no_results():
+    assert Map().find("london", 10) == []
+
+
+def test_empty_string_returns_no_results():
+    assert Map().find("", 10) == []
+
+
+def test_limit_option():
+    m = Map()
+    for idx in range(5):
+        m.put("london", idx, 0)
+    assert len(m.find("london", 2)) == 2
+
+
+def test_duplicated_references():
+    m = Map()
+    m.put("london", 123)
+    m.put("london2", 123)
+    r = m.find("london", 10)
+    assert len(r) == 1 and r[0][0] == 123
+
+
+def test_perfect_match():
+    m = Map()
+    m.put("london", 123, 0)
+    assert m.find("london")[0] == [123, 7, 6]
+
+
+def test_favours_exact_matches():
+    m = Map()
+    m.put("lon", 125, 0)
+    m.put("london city airport", 124, 0)
+    m.put("london", 123, 0)
+    assert m.find("london")[0][0] == 123
+
+
+@pytest.mark.parametrize("needle", ["lonXdon", "lodon", "lodnon"])
+def test_misspelt(needle):
+    m = Map()
+    m.put("london", 123, 0)
+    assert m.find(needle) != []
+
+
+def test_sorts_by_descending_matchiness():
+    m = Map()
+    m.put("New York", 1001, 0)
+    m.put("Yorkshire", 1002, 0)
+    m.put("York", 1003, 0)
+    m.put("Yorkisthan", 1004, 0)
+    assert m.find("York") == [[1003, 5, 4], [1001, 4, 8], [1002, 4, 9], [1004, 4, 10]]
+
+
+def test_favours_lighter():
+    m = Map()
+    m.put("london", 103, 103)
+    m.put("london", 101, 101)
+    m.put("london", 102, 102)
+    assert [r[0] for r in m.find("london")] == [101, 102, 103]
+
+
+def test_tie_is_reference_ascending():
+    """spec/integration_spec.rb:31-42."""
+    m = Map()
+    m.put("paris", 456)
+    m.put("paris", 123)
+    assert m.find("paris") == [[123, 6, 5], [456, 6, 5]]
+    assert m.find("pariis")[0] == [123, 5, 5]
+
+
+def test_command_processor_vector():
+    """spec/blurrily/command_processor_spec.rb:15-19."""
+    m = Map()
+    m.put("great london", 12)
+    m.put("greater masovian", 13)
+    assert m.find("great") == [[12, 6, 12], [13, 5, 16]]
+
+
+def test_put_find_delete_cycle():
+    """spec/blurrily/map_spec.rb:377-384 (smaller count: every step rebuilds the device index)."""
+    m = Map()
+    for index in range(64):
+        m.put("Port-au-Prince", index)
+        assert m.stats()["references"] == 1
+        assert m.find("Port-au-Prince")[0][0] == index
+        m.delete(index)
+        assert m.find("Port-au-Prince") == []
+
+
+# ---- seeded random haystacks vs the oracle ------------------------------------------------
+
+def _check_batch(m, o, needles, limit):
+    packed = b"".join(needles)
+    off = np.zeros(len(needles) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in needles])
+    rows, counts = m.find_batch_packed(packed, off, limit)
+    for i, nd in enumerate(needles):
+        want = o.find(nd, limit)
+        got = rows[i, :counts[i]].tolist()
+        assert got == want, (nd, limit, got[:5], want[:5])
+
+
+@pytest.mark.parametrize("n,limit", [(1, 10), (50, 3), (3000, 10), (70000, 10), (140000, 100)])
+def test_words_vs_oracle(n, limit):
+    hay, off = W.words(n, seed=100 + n)
+    strings = W.unpack(hay, off)
+    m, o = build_pair(strings)
+    q, qo = W.queries(hay, off, 400, seed=7)
+    _check_batch(m, o, W.unpack(q, qo) + [b"", b"zzzz", b"a"], limit)
+
+
+def test_sparse_refs_weights_and_ties():
+    rng = np.random.default_rng(5)
+    hay, off = W.skewed(30000, seed=9)
+    strings = W.unpack(hay, off)
+    refs = rng.choice(2**31 - 1, size=len(strings), replace=False).astype(np.int64) + 1
+    weights = rng.integers(0, 4, size=len(strings))           # 0 -> strlen, else tiny: massive ties
+    m, o = build_pair(strings, refs.tolist(), weights.tolist())
+    q, qo = W.queries(hay, off, 300, seed=10)
+    for limit in (1, 10, 100, 1024):
+        _check_batch(m, o, W.unpack(q, qo)[:100], limit)
+
+
+def test_large_limits_multi_pass():
+    hay, off = W.skewed(5000, seed=19)
+    m, o = build_pair(W.unpack(hay, off))
+    q, qo = W.queries(hay, off, 20, seed=20)
+    for limit in (1025, 3000, 65535):
+        _check_batch(m, o, W.unpack(q, qo), limit)
+
+
+def test_long_needles_use_wide_counters():
+    hay, off = W.geonames(20000, 3000, seed=3)
+    strings = W.unpack(hay, off)
+    m, o = build_pair(strings)
+    long1 = b" ".join(strings[:40])            # > 127 distinct trigrams
+    long2 = (b"abcdefghijklmnopqrstuvwxyz " * 40)[:1000]
+    _check_batch(m, o, [long1, long2, strings[0], b"x" * 300], 10)
+    _check_batch(m, o, [long1, long2], 300)
+
+
+def test_arbitrary_bytes_needles():
+    hay, off = W.words(5000, seed=77)
+    m, o = build_pair(W.unpack(hay, off))
+    needles = [b"Lond\xc3\xa9n", b"a*b c", b"***", b"  ", b"UPPER lower", bytes(range(1, 60))]
+    _check_batch(m, o, needles, 10)

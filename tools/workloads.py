@@ -1,0 +1,68 @@
+"""ctypes front-end of tools/synth.cpp: the seeded workloads of BASELINE.json's configs.
+
+Bench/test infrastructure (not part of the product).  Every generator returns
+``(packed: np.ndarray[uint8], offsets: np.ndarray[uint64, n+1])``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def _synth():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libblurrily_synth.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} missing: run __graft_entry__.build()")
+        L = C.CDLL(path)
+        L.synth_max_bytes.restype = C.c_uint64
+        L.synth_max_bytes.argtypes = [C.c_uint32]
+        for name, args in {
+            "synth_words": [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
+            "synth_geonames": [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
+            "synth_skewed": [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
+            "synth_queries": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
+        }.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_uint64
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _run(n, call):
+    L = _synth()
+    buf = np.empty(int(L.synth_max_bytes(n)), dtype=np.uint8)
+    off = np.empty(n + 1, dtype=np.uint64)
+    used = call(L, buf.ctypes.data, off.ctypes.data)
+    return buf[:used].copy(), off
+
+
+def words(n=235886, seed=1):
+    """configs[0..1]: distinct pseudo-words (stand-in for /usr/share/dict/words)."""
+    return _run(n, lambda L, b, o: L.synth_words(seed, n, b, o))
+
+
+def geonames(n=8423769, vocab=500000, seed=3):
+    """configs[2..3]: Geonames-scale multi-word haystack."""
+    return _run(n, lambda L, b, o: L.synth_geonames(seed, n, vocab, b, o))
+
+
+def skewed(n=4000000, seed=5):
+    """configs[4]: hot-trigram haystack with massive (matches, weight) ties."""
+    return _run(n, lambda L, b, o: L.synth_skewed(seed, n, b, o))
+
+
+def queries(hay, hay_off, n, seed):
+    """Haystack samples with 0..2 random edits."""
+    n_hay = len(hay_off) - 1
+    return _run(n, lambda L, b, o: L.synth_queries(seed, hay.ctypes.data, hay_off.ctypes.data, n_hay, n, b, o))
+
+
+def unpack(packed, offsets):
+    raw = packed.tobytes()
+    return [raw[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
