@@ -172,6 +172,23 @@ int oracle_put(void* h, const char* needle, uint32_t ref, uint32_t weight) {
   return n;
 }
 
+/* n puts in one call (refs 1..n when `refs` is NULL); needles are
+ * packed[offsets[i] .. offsets[i+1]).  Test/bench convenience only. */
+long oracle_put_many(void* h, const char* packed, const uint64_t* offsets, const uint32_t* refs, size_t n) {
+  long total = 0;
+  size_t cap = 256;
+  char* tmp = (char*)malloc(cap);
+  for (size_t i = 0; i < n; ++i) {
+    size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+    if (len + 1 > cap) { cap = (len + 1) * 2; tmp = (char*)realloc(tmp, cap); }
+    memcpy(tmp, packed + offsets[i], len);
+    tmp[len] = 0;
+    total += oracle_put(h, tmp, refs ? refs[i] : (uint32_t)(i + 1), 0);
+  }
+  free(tmp);
+  return total;
+}
+
 /* storage.c:584-612: drop every entry of `ref` (swap with last). */
 int oracle_delete(void* h, uint32_t ref) {
   ora_map_t* m = (ora_map_t*)h;

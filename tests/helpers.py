@@ -37,6 +37,8 @@ class Oracle:
             L.oracle_tokenise.argtypes = [C.c_char_p, C.c_void_p]
             L.oracle_nb_entries.argtypes = [C.c_void_p, C.c_char_p]
             L.oracle_nb_entries.restype = C.c_uint64
+            L.oracle_put_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+            L.oracle_put_many.restype = C.c_long
             cls._lib = L
         return cls._lib
 
@@ -51,6 +53,10 @@ class Oracle:
 
     def put(self, needle, ref, weight=0):
         return self.L.oracle_put(self.h, needle, ref, weight)
+
+    def put_many(self, packed, offsets, refs=None):
+        return self.L.oracle_put_many(self.h, packed.ctypes.data, offsets.ctypes.data,
+                                      None if refs is None else refs.ctypes.data, len(offsets) - 1)
 
     def delete(self, ref):
         return self.L.oracle_delete(self.h, ref)

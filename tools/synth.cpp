@@ -134,7 +134,7 @@ uint64_t synth_geonames(uint64_t seed, uint32_t n, uint32_t vocab, char* out, ui
   for (uint32_t i = 0; i < n; ++i) {
     offsets[i] = pos;
     const uint32_t x = r.below(100);
-    const uint32_t nw = x < 25 ? 1 : x < 67 ? 2 : x < 92 ? 3 : 4;   // mean 2.16 words
+    const uint32_t nw = x < 31 ? 1 : x < 72 ? 2 : x < 93 ? 3 : 4;   // mean 2.04 words
     for (uint32_t k = 0; k < nw; ++k) {
       const double u = r.unit() * acc;
       const uint32_t wi = uint32_t(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
@@ -198,6 +198,28 @@ uint64_t synth_queries(uint64_t seed, const char* hay, const uint64_t* hay_off, 
   }
   offsets[n_q] = pos;
   return pos;
+}
+
+// Sum over needles of the number of distinct trigrams (T of tokeniser.c:119),
+// for the 8 B x T term of the algorithmic byte count.
+uint64_t synth_count_trigrams(const char* packed, const uint64_t* offsets, uint32_t n) {
+  uint64_t total = 0;
+  std::vector<uint16_t> codes;
+  for (uint32_t i = 0; i < n; ++i) {
+    const char* s = packed + offsets[i];
+    const size_t len = size_t(offsets[i + 1] - offsets[i]);
+    codes.clear();
+    uint32_t a = 0, b = 0;
+    for (size_t k = 0; k <= len; ++k) {
+      const unsigned char ch = k < len ? (unsigned char)s[k] : 0;
+      const uint32_t c = (ch >= 'a' && ch <= 'z') ? uint32_t(ch - 'a' + 1) : 0u;
+      codes.push_back(uint16_t(a + 28u * b + 784u * c));
+      a = b; b = c;
+    }
+    std::sort(codes.begin(), codes.end());
+    total += uint64_t(std::unique(codes.begin(), codes.end()) - codes.begin());
+  }
+  return total;
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ def _synth():
             "synth_geonames": [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
             "synth_skewed": [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
             "synth_queries": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
+            "synth_count_trigrams": [C.c_void_p, C.c_void_p, C.c_uint32],
         }.items():
             fn = getattr(L, name)
             fn.restype = C.c_uint64
@@ -66,3 +67,8 @@ def queries(hay, hay_off, n, seed):
 def unpack(packed, offsets):
     raw = packed.tobytes()
     return [raw[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
+
+
+def count_trigrams(packed, offsets):
+    """Sum of distinct-trigram counts over the needles."""
+    return int(_synth().synth_count_trigrams(packed.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
