@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblurrily_hip.so")
+# BLURRILY_LIB selects another build of the same library (the phase-profile build of tools/)
+LIB_PATH = os.environ.get("BLURRILY_LIB") or os.path.join(_HERE, "libblurrily_hip.so")
 
 
 class TrigramMatch(C.Structure):

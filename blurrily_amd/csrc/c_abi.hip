@@ -59,6 +59,10 @@ struct trigram_map_t {
 
 namespace {
 
+#ifdef BLURRILY_PHASE_PROFILE
+unsigned long long* g_phase_clocks = nullptr;
+#endif
+
 int ensure_device(trigram_map m) {
   if (m->dev.device >= 0 && m->dev.built_from == m->host->generation()) return 0;
   if (device_index_build(*m->host, &m->dev) < 0) return -1;
@@ -85,18 +89,15 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   if (m->ws_codes.reserve(align_up(code_slots * sizeof(uint16_t), 256), stream) < 0) return -1;
   const size_t per_n = align_up(n * sizeof(uint32_t), 256);
   const bool multi_pass = limit > 256;             // long needles keep 256 rows per pass, short ones 1024
-  const size_t small_bytes = per_n * 3 + (multi_pass ? align_up(n * 8, 256) + per_n : 0) + 256;
+  const size_t small_bytes = per_n * 3 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
   if (m->ws_small.reserve(small_bytes, stream) < 0) return -1;
   unsigned char* sp = static_cast<unsigned char*>(m->ws_small.p);
   uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1..]=queues
   uint32_t* q_ntri   = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* q_nb_ws  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* big_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
-  unsigned long long* floor_hi = nullptr; uint32_t* floor_rk = nullptr;
-  if (multi_pass) {
-    floor_hi = reinterpret_cast<unsigned long long*>(sp);          sp += align_up(n * 8, 256);
-    floor_rk = reinterpret_cast<uint32_t*>(sp);
-  }
+  unsigned long long* floor = nullptr;
+  if (multi_pass) floor = reinterpret_cast<unsigned long long*>(sp);
   uint32_t* q_nb = d_nb ? d_nb : q_nb_ws;
   BLURRILY_HIP_TRY(hipMemsetAsync(scalars, 0, 256, stream));
 
@@ -114,7 +115,16 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
   a.offsets = d_offsets; a.qcodes = static_cast<const uint16_t*>(m->ws_codes.p);
   a.q_ntri = q_ntri; a.q_nb = q_nb; a.results = d_results; a.counts = d_counts; a.limit = limit;
-  a.floor_hi = floor_hi; a.floor_rk = floor_rk;
+  a.floor = floor;
+#ifdef BLURRILY_PHASE_PROFILE
+  {
+    static unsigned long long* d_phase = nullptr;
+    if (!d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phase), 8192 * 8 * 8));
+    BLURRILY_HIP_TRY(hipMemsetAsync(d_phase, 0, 8192 * 8 * 8, stream));
+    a.phase_clocks = d_phase;
+    g_phase_clocks = d_phase;
+  }
+#endif
   // every launch gets its own zeroed queue word (scalars[1..63]); recycled in stream order
   uint32_t queue_slot = 1;
   auto next_queue = [&]() -> uint32_t* {
@@ -321,5 +331,14 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
 }
 
 void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabled != 0; }
+
+#ifdef BLURRILY_PHASE_PROFILE
+// profiling builds only: copy out the per-workgroup phase clocks of the last find launch
+int blurrily_debug_phase_clocks(unsigned long long* out, size_t n_workgroups) {
+  if (!g_phase_clocks) return -1;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(out, g_phase_clocks, n_workgroups * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

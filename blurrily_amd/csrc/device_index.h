@@ -1,16 +1,24 @@
 // device_index.h -- the read-only, HBM-resident form of the trigram index.
 //
 // Layout (see DESIGN.md "Data layout in HBM"):
-//   * references are compacted to ranks 0..N-1 in ascending reference order
-//     (monotone, so "rank ascending" == the reference's tie order "ref
-//     ascending", spec/integration_spec.rb:37-42); ref_of_rank / weight_of_rank
-//     are the side tables (a reference has one weight in every bucket:
-//     storage.c:418 writes the same {reference, weight} into each of them).
-//   * the rank space is cut into windows of 2^window_bits ranks; the postings
-//     are stored window-major: for window w, for trigram code t, the sorted
-//     16-bit in-window ranks of the references whose string contains t.
+//   * references are compacted to ranks 0..N-1 in ascending (weight, reference)
+//     order.  A reference has one weight in every bucket (storage.c:418 writes
+//     the same {reference, weight} into each of them), so the reference's
+//     result order -- matches descending, weight ascending (storage.c:129-138),
+//     reference ascending among full ties (spec/integration_spec.rb:37-42) --
+//     is exactly "matches descending, rank ascending": the kernel never needs
+//     a weight while it counts and selects.  ref_of_rank / weight_of_rank are
+//     the side tables read when result rows are written.
+//   * the rank space is cut into windows of kWindowRanks = 65 535 ranks; the
+//     postings are stored window-major: for window w, for trigram code t, the
+//     16-bit in-window ranks (in no particular order: counting does not care)
+//     of the references whose string contains t.
 //     slice_off[w * kNumCodes + t] is the start of that slice in `ent`
 //     (a CSR over (window, code)); one extra element closes the last slice.
+//     Every slice starts on a 16-byte boundary and is padded to a multiple of
+//     eight entries with the sentinel 0xFFFF (the one in-window rank no
+//     reference uses), so the kernel counts whole 16-byte groups without any
+//     range check; counter slot 0xFFFF is a scratch slot the scan ignores.
 //   * code_total[t] = used[t] of the reference's bucket t (storage.c:501), for
 //     the matched-entries metric.
 // An entry costs 2 bytes in HBM instead of the reference's 8-byte
@@ -23,21 +31,24 @@
 
 namespace blurrily {
 
-constexpr uint32_t kWindowBits = 16;
-constexpr uint32_t kWindowSize = 1u << kWindowBits;
+constexpr uint32_t kWindowBits  = 16;
+constexpr uint32_t kWindowSize  = 1u << kWindowBits;    // counter slots per window (LDS)
+constexpr uint32_t kWindowRanks = kWindowSize - 1;      // ranks per window; slot 0xFFFF = padding sentinel
+constexpr uint16_t kPadRank     = 0xFFFF;
 constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byte over-reads)
 
 struct DeviceIndex {
   int       device        = -1;
   uint32_t  n_refs        = 0;
   uint32_t  n_windows     = 0;
-  uint64_t  n_entries     = 0;
+  uint64_t  n_entries     = 0;        // real postings (padding excluded)
+  uint64_t  n_slots       = 0;        // entries of `ent` including slice padding
   uint64_t  device_bytes  = 0;
   uint64_t  built_from    = 0;        // HostIndex::generation() this was built from
   uint32_t* d_ref_of_rank    = nullptr;   // [n_refs]
   uint32_t* d_weight_of_rank = nullptr;   // [n_refs]
   uint32_t* d_slice_off      = nullptr;   // [n_windows * kNumCodes + 1]
-  uint16_t* d_ent            = nullptr;   // [n_entries + kEntPad]
+  uint16_t* d_ent            = nullptr;   // [n_slots + kEntPad]
   uint32_t* d_code_total     = nullptr;   // [kNumCodes]
 };
 

@@ -91,10 +91,23 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   const uint64_t n_refs64 = refs.size();
   if (n_refs64 > 0xFFFFFFFFull || nnz > 0xFFFFFFF0ull) { errno = EPROTO; return -1; }
   const uint32_t n_refs = uint32_t(n_refs64);
-  const uint32_t n_win  = std::max<uint32_t>(1u, uint32_t((n_refs64 + kWindowSize - 1) >> kWindowBits));
+  const uint32_t n_win  = std::max<uint32_t>(1u, uint32_t((n_refs64 + kWindowRanks - 1) / kWindowRanks));
 
+  // ranks follow (weight, reference); sorted_ref / rank_of_pos map a reference to its rank
+  std::vector<uint32_t> sorted_ref(n_refs), rank_of_pos(n_refs);
   std::vector<uint32_t> ref_of_rank(n_refs), weight_of_rank(n_refs);
-  for (uint32_t i = 0; i < n_refs; ++i) { ref_of_rank[i] = refs[i].ref; weight_of_rank[i] = refs[i].weight; }
+  {
+    std::vector<uint32_t> order(n_refs);
+    for (uint32_t i = 0; i < n_refs; ++i) { order[i] = i; sorted_ref[i] = refs[i].ref; }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t l, uint32_t r) { return refs[l].weight < refs[r].weight; });  // refs[] is ref-ascending
+    for (uint32_t rk = 0; rk < n_refs; ++rk) {
+      const uint32_t pos = order[rk];
+      rank_of_pos[pos] = rk;
+      ref_of_rank[rk] = refs[pos].ref;
+      weight_of_rank[rk] = refs[pos].weight;
+    }
+  }
   std::vector<Entry>().swap(refs);
 
   // ---- 2. rank every posting, count per (window, code) ----------------------
@@ -111,30 +124,37 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
       code_total[t] = bk.used;
       if (!bk.used) continue;
       const Entry* e = sorted_view(bk, scratch);
-      uint64_t pos = 0;                       // ranks ascend inside a bucket: gallop from the last hit
+      uint64_t pos = 0;                       // references ascend inside a bucket: gallop from the last hit
       for (uint32_t j = 0; j < bk.used; ++j) {
         const uint32_t ref = e[j].ref;
         uint64_t lo = pos, step = 1;
-        while (lo + step < n_refs && ref_of_rank[lo + step] < ref) { lo += step; step <<= 1; }
+        while (lo + step < n_refs && sorted_ref[lo + step] < ref) { lo += step; step <<= 1; }
         uint64_t hi = std::min<uint64_t>(lo + step, n_refs ? n_refs - 1 : 0);
-        while (lo < hi) {                     // first rank in [lo, hi] with ref_of_rank >= ref
+        while (lo < hi) {                     // first position in [lo, hi] with sorted_ref >= ref
           const uint64_t mid = (lo + hi) >> 1;
-          if (ref_of_rank[mid] < ref) lo = mid + 1; else hi = mid;
+          if (sorted_ref[mid] < ref) lo = mid + 1; else hi = mid;
         }
-        if (lo >= n_refs || ref_of_rank[lo] != ref || weight_of_rank[lo] != e[j].weight ||
-            (j > 0 && lo < pos)) {
-          errno = EPROTO; return -1;
-        }
-        rank[idx++] = uint32_t(lo);
-        slice_off[(lo >> kWindowBits) * kNumCodes + t + 1] += 1;
+        if (lo >= n_refs || sorted_ref[lo] != ref || (j > 0 && lo < pos)) { errno = EPROTO; return -1; }
+        const uint32_t rk = rank_of_pos[lo];
+        if (weight_of_rank[rk] != e[j].weight) { errno = EPROTO; return -1; }   // one weight per reference
+        rank[idx++] = rk;
+        slice_off[uint64_t(rk / kWindowRanks) * kNumCodes + t + 1] += 1;
         pos = lo + 1;                         // strictly ascending: a duplicate ref fails the lookup above
       }
     }
   }
-  for (uint64_t i = 0; i < n_slices; ++i) slice_off[i + 1] += slice_off[i];
+  // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum
+  uint64_t n_slots = 0;
+  for (uint64_t i = 0; i < n_slices; ++i) {
+    const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
+    slice_off[i + 1] = 0;                     // becomes the running end below
+    n_slots += len;
+    if (n_slots > 0xFFFF0000ull) { errno = EPROTO; return -1; }
+    slice_off[i + 1] = uint32_t(n_slots);
+  }
 
   // ---- 3. scatter into window-major slices ----------------------------------
-  std::vector<uint16_t> ent(nnz + kEntPad, 0);
+  std::vector<uint16_t> ent(n_slots + kEntPad, kPadRank);
   {
     std::vector<uint32_t> cursor(slice_off.begin(), slice_off.end() - 1);
     uint64_t idx = 0;
@@ -142,7 +162,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
       const uint32_t used = host.bucket(t).used;
       for (uint32_t j = 0; j < used; ++j) {
         const uint32_t r = rank[idx++];
-        ent[cursor[uint64_t(r >> kWindowBits) * kNumCodes + t]++] = uint16_t(r & (kWindowSize - 1));
+        ent[cursor[uint64_t(r / kWindowRanks) * kNumCodes + t]++] = uint16_t(r % kWindowRanks);
       }
     }
   }
@@ -150,7 +170,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
 
   // ---- 4. upload -------------------------------------------------------------
   DeviceIndex ix;
-  ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz;
+  ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz; ix.n_slots = n_slots;
   ix.built_from = host.generation();
   auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {
     using T = typename std::remove_reference<decltype(v)>::type::value_type;

@@ -46,11 +46,12 @@ struct FindArgs {
   uint32_t        keep;        // rows wanted from this pass
   uint32_t        pass_base;   // rows already delivered by earlier passes
   uint32_t        pool_cap;    // power of two, >= 4*keep
-  unsigned long long* floor_hi;  // [n] last key of the previous pass (multi-pass only)
-  uint32_t*       floor_rk;
+  unsigned long long* floor;   // [n] last key delivered by the previous pass (multi-pass only)
+  unsigned long long* phase_clocks;  // profiling builds only (make profile), else nullptr
 };
 
 uint32_t find_pool_cap(uint32_t keep);
+int find_threads();   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 

@@ -39,12 +39,26 @@
 
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 
 namespace blurrily {
 
 namespace {
 
 constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
+
+// Optional phase profile (make profile): wave 0's shader-clock time per phase of the sweep,
+// accumulated per workgroup into FindArgs::phase_clocks[blockIdx.x * 8 + phase].
+#ifdef BLURRILY_PHASE_PROFILE
+#define PHASE_DECL unsigned long long ph_last = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(i) do { const unsigned long long t_ = clock64(); ph_acc[i] += t_ - ph_last; ph_last = t_; } while (0)
+#define PHASE_FLUSH(A) do { if (threadIdx.x == 0 && (A).phase_clocks) { \
+    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(A).phase_clocks[blockIdx.x * 8 + i_], ph_acc[i_]); } } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#define PHASE_FLUSH(A)
+#endif
 constexpr uint64_t kKeyInf    = ~0ull;
 
 // --------------------------------------------------------------- tokeniser ---
@@ -128,13 +142,14 @@ template <> struct Packing<uint16_t> {
                             kTop = 0x8000u, kMask = 0xFFFFu;
 };
 
+// A candidate is one 64-bit key: (T - matches) in the high word, rank in the low word.  Ranks
+// follow (weight, reference), so ascending keys are the reference's result order.
 struct Control {            // workgroup-shared scalars
-  unsigned long long thr_hi;
-  uint32_t thr_rk;
+  unsigned long long thr;   // admission threshold: the keep-th best key seen (kKeyInf: none yet)
+  unsigned long long floor; // keys at or before this one were delivered by earlier passes
   uint32_t pool_n;
   uint32_t overflow;
   uint32_t q;
-  uint32_t nonempty[3];
 };
 
 template <typename CT>
@@ -145,37 +160,35 @@ __device__ __forceinline__ void bump(uint32_t* cnt32, uint32_t r) {
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Count one 16-byte group of eight 16-bit in-window ranks; `c` is the entry
-// index of its first element, [a, b) the live range of the slice.
+// Count one 16-byte group: eight 16-bit in-window ranks, every one of them either a real
+// rank or the padding sentinel 0xFFFF (whose counter slot the scan ignores) -- no range
+// checks.  A lane that had nothing to load holds eight sentinels and skips the group.
+__device__ __forceinline__ bool group_live(const uint4 v) { return (v.x & 0xFFFFu) != kPadRank; }
+
 template <typename CT>
-__device__ __forceinline__ void bump8(uint32_t* cnt32, const uint4 v, uint32_t c, uint32_t a, uint32_t b) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  if (c >= a && c + 8 <= b) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bump<CT>(cnt32, w[j] & 0xFFFFu);
-      bump<CT>(cnt32, w[j] >> 16);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t i0 = c + 2 * j, i1 = i0 + 1;
-      if (i0 >= a && i0 < b) bump<CT>(cnt32, w[j] & 0xFFFFu);
-      if (i1 >= a && i1 < b) bump<CT>(cnt32, w[j] >> 16);
-    }
-  }
+__device__ __forceinline__ void bump8(uint32_t* cnt32, const uint4 v) {
+  if (!group_live(v)) return;
+  bump<CT>(cnt32, v.x & 0xFFFFu); bump<CT>(cnt32, v.x >> 16);
+  bump<CT>(cnt32, v.y & 0xFFFFu); bump<CT>(cnt32, v.y >> 16);
+  bump<CT>(cnt32, v.z & 0xFFFFu); bump<CT>(cnt32, v.z >> 16);
+  bump<CT>(cnt32, v.w & 0xFFFFu); bump<CT>(cnt32, v.w >> 16);
 }
 
-// Sort the candidate pool ascending by (hi, rank), keep the best `keep`, and
-// tighten the admission threshold.  Called by all threads of the workgroup.
+__device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uint32_t b) {
+  uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+  if (c < b) v = *reinterpret_cast<const uint4*>(ent + c);
+  return v;
+}
+
+// Sort the candidate pool ascending, keep the best `keep`, and tighten the admission
+// threshold.  Called by all threads of the workgroup.
 template <int NT>
-__device__ void compact_pool(unsigned long long* pool_hi, uint32_t* pool_rk, Control* ctl,
-                             uint32_t cap, uint32_t keep) {
+__device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t cap, uint32_t keep) {
   const uint32_t tid = threadIdx.x;
   const uint32_t n = min(ctl->pool_n, cap);
   uint32_t P = 1;
   while (P < n) P <<= 1;
-  for (uint32_t i = n + tid; i < P; i += NT) { pool_hi[i] = kKeyInf; pool_rk[i] = 0xFFFFFFFFu; }
+  for (uint32_t i = n + tid; i < P; i += NT) pool[i] = kKeyInf;
   __syncthreads();
   for (uint32_t size = 2; size <= P; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -183,10 +196,8 @@ __device__ void compact_pool(unsigned long long* pool_hi, uint32_t* pool_rk, Con
         const uint32_t lo = 2 * i - (i & (stride - 1));
         const uint32_t hi = lo + stride;
         const bool asc = (lo & size) == 0;
-        const unsigned long long ah = pool_hi[lo], bh = pool_hi[hi];
-        const uint32_t ar = pool_rk[lo], br = pool_rk[hi];
-        const bool gt = (ah > bh) || (ah == bh && ar > br);
-        if (gt == asc) { pool_hi[lo] = bh; pool_hi[hi] = ah; pool_rk[lo] = br; pool_rk[hi] = ar; }
+        const unsigned long long x = pool[lo], y = pool[hi];
+        if ((x > y) == asc) { pool[lo] = y; pool[hi] = x; }
       }
       __syncthreads();
     }
@@ -194,34 +205,332 @@ __device__ void compact_pool(unsigned long long* pool_hi, uint32_t* pool_rk, Con
   if (tid == 0) {
     ctl->pool_n = min(n, keep);
     ctl->overflow = 0;
-    if (n >= keep && keep > 0) { ctl->thr_hi = pool_hi[keep - 1]; ctl->thr_rk = pool_rk[keep - 1]; }
+    if (n >= keep && keep > 0) ctl->thr = pool[keep - 1];
   }
   __syncthreads();
 }
 
+// State of one needle's sweep that every phase needs.
+struct Needle {
+  uint32_t T;                       // distinct trigrams
+  bool has_floor;                   // later pass of a limit larger than the pool (floor key in Control)
+};
+
+// ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
 template <typename CT, int NT>
-__global__ __launch_bounds__(NT) void find_kernel(const FindArgs A) {
+__device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd, uint4* cnt128,
+                                            unsigned long long* pool, Control* ctl, uint32_t wbase,
+                                            uint32_t wlen) {
   using P = Packing<CT>;
+  constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
+  const uint32_t tid = threadIdx.x;
+  const unsigned long long thr = ctl->thr;
+  // A counter must reach `need` to beat the current keep-th candidate: its match count, or one
+  // more once the sweep has passed that candidate's rank (ties lose to the lower rank).
+  uint32_t need = 1;
+  if (thr != kKeyInf) {
+    const uint32_t matches_k = nd.T - uint32_t(thr >> 32);
+    need = max(1u, uint32_t(thr) >= wbase ? matches_k : matches_k + 1);
+  }
+  const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
+  if (need <= nd.T) {
+    const uint32_t bias = (P::kTop - need) * P::kOnes;
+    // slow path of one vector: some counter reached `need`
+    auto harvest = [&](const uint4 v, const uint32_t i) {
+      auto word = [&](const uint32_t wv, const uint32_t j) {
+        uint32_t m = (wv + bias) & P::kHi;
+        while (m) {
+          const uint32_t bit = __ffs(m) - 1;
+          m &= m - 1;
+          const uint32_t pos = bit / P::kBits;
+          const uint32_t cnt = (wv >> (pos * P::kBits)) & P::kMask;
+          const uint32_t rank = wbase + (i * 4 + j) * P::kPerWord + pos;
+          const unsigned long long key = (static_cast<unsigned long long>(nd.T - cnt) << 32) | rank;
+          bool pass = key <= thr;
+          if (nd.has_floor) pass = pass && key > ctl->floor;
+          if (pass) {
+            const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
+            if (at < A.pool_cap) pool[at] = key;
+            else ctl->overflow = 1;
+          }
+        }
+      };
+      word(v.x, 0); word(v.y, 1); word(v.z, 2); word(v.w, 3);
+    };
+    // one SWAR test per vector: the top bit of a lane is set iff its counter >= need
+    auto test = [&](uint4 v, const uint32_t i) {
+      if (i == kVecs - 1) v.w &= ~(P::kMask << (32 - P::kBits));      // slot 0xFFFF counts padding
+      const uint32_t hit = ((v.x + bias) | (v.y + bias) | (v.z + bias) | (v.w + bias)) & P::kHi;
+      if (hit) harvest(v, i);
+    };
+    for (uint32_t i = tid; i < nvec; i += NT) {
+      const uint4 v = cnt128[i];
+      // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held
+      // in four VGPRs for the whole sweep and spilled to scratch under the 64-VGPR budget.
+      uint32_t z = 0;
+      asm volatile("" : "+v"(z));
+      cnt128[i] = make_uint4(z, z, z, z);
+      test(v, i);
+    }
+  } else {
+    // nothing in this window can enter the pool any more: just clear the counters
+    for (uint32_t i = tid; i < nvec; i += NT) {
+      uint32_t z = 0;
+      asm volatile("" : "+v"(z));
+      cnt128[i] = make_uint4(z, z, z, z);
+    }
+  }
+  // a short window does not reach the vector holding the padding slot: clear it here
+  if (nvec < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+}
+
+// ---- select: keep the pool small and the threshold tight.  Returns true when the pool
+// overflowed during the scan of this window, i.e. the window has to be swept again.
+template <int NT>
+__device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned long long* pool, Control* ctl,
+                                                  uint32_t wbase) {
+  const uint32_t ov = ctl->overflow;
+  const uint32_t pn = ctl->pool_n;
+  if (!(ov || pn > A.pool_cap / 2)) return false;
+  compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+  if (!ov) return false;
+  // The pool overflowed mid-window: candidates of this window were lost.  Keep the
+  // tightened threshold (the keep-th best of a subset is a valid bound), forget this
+  // window's survivors and sweep the window again.
+  if (threadIdx.x == 0) {
+    uint32_t j = 0;
+    const uint32_t n = ctl->pool_n;
+    for (uint32_t i = 0; i < n; ++i)
+      if (uint32_t(pool[i]) < wbase) pool[j++] = pool[i];
+    ctl->pool_n = j;
+  }
+  __syncthreads();
+  return true;
+}
+
+// Every slice (already padded to whole 16-byte groups) is cut into units of 64 groups
+// (512 postings, 1 KiB per wave-load).  Unit j of slice t belongs to wave (t + j) mod kNW: one
+// hot trigram is streamed by the whole workgroup and a needle's many small slices spread over
+// the waves.
+__device__ __forceinline__ uint32_t slice_units(uint32_t a, uint32_t b) { return (((b - a) >> 3) + 63) >> 6; }
+
+// ---- LDS-table flavour (needles with more than 128 distinct trigrams) ---------------------
+// Streams every unit of this wave for the slices staged in s_a/s_b.  Returns true if the
+// window holds any posting of those slices.
+template <typename CT, int kNW>
+__device__ __forceinline__ bool count_window(const FindArgs& A, uint32_t* cnt32, const uint32_t* s_a,
+                                             const uint32_t* s_b, uint32_t tc, uint32_t wid, uint32_t lane) {
+  bool any = false;
+  for (uint32_t t = 0; t < tc; ++t) {
+    const uint32_t a = __builtin_amdgcn_readfirstlane(s_a[t]);
+    const uint32_t b = __builtin_amdgcn_readfirstlane(s_b[t]);
+    if (a == b) continue;
+    any = true;
+    const uint32_t su = slice_units(a, b);
+    for (uint32_t j = (wid - t) & (kNW - 1); j < su; j += kNW)
+      bump8<CT>(cnt32, load_group(A.ent, a + (j * 64 + lane) * 8, b));
+  }
+  return any;
+}
+
+// Sweep for needles whose trigrams need several staging chunks (> 128 distinct trigrams).
+template <typename CT, int NT>
+__device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
+                              unsigned long long* pool, uint32_t* s_tab, Control* ctl) {
   constexpr uint32_t kNW = NT / 64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint32_t* s_a = s_tab;
+  uint32_t* s_b = s_tab + kCodeChunk;
+  for (uint32_t w = 0; w < A.n_windows; ++w) {
+    const uint32_t wbase = w * kWindowRanks;
+    const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+    const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
+    bool redo;
+    do {
+      redo = false;
+      bool touched = false;
+      for (uint32_t c0 = 0; c0 < nd.T; c0 += kCodeChunk) {
+        const uint32_t tc = min(kCodeChunk, nd.T - c0);
+        if (tid < tc) {
+          const uint32_t code = codes[c0 + tid];
+          s_a[tid] = soff[code]; s_b[tid] = soff[code + 1];
+        }
+        __syncthreads();
+        touched |= count_window<CT, kNW>(A, cnt32, s_a, s_b, tc, wid, lane);
+        __syncthreads();                                        // counts visible; s_a/s_b reusable
+      }
+      if (!touched) break;                                      // nothing of this needle in the window
+      scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
+      __syncthreads();
+      redo = select_after_scan<NT>(A, pool, ctl, wbase);
+    } while (redo);
+  }
+}
+
+// ---- register-table flavour (needles with <= 128 distinct trigrams: every real needle) -----
+// A needle's slice table for one window, held in registers: lane t owns slice t (slot 0) and
+// slice t+64 (slot 1); every wave keeps its own copy, so walking the table needs neither LDS
+// nor a barrier, and a wave finds its units lane-parallel (one ballot per slot): the cost
+// follows the units it owns, not T.
+// The units of this wave inside one slot of the table (a, b: the slot's per-lane slice bounds).
+// UNIT_BODY sees: k (ordinal of the unit within this wave), c (entry index of the lane's
+// 16-byte group), sb (end of the slice).  Plain macro rather than a callback: closures that
+// capture registers by reference end up in scratch memory.
+#define BLURRILY_FOR_SLOT_UNITS(kNW, a, b, wid, lane, k, UNIT_BODY)                              \
+  do {                                                                                           \
+    unsigned long long mask_ = __ballot((((wid) - (lane)) & ((kNW) - 1)) < slice_units((a), (b))); \
+    while (mask_) {                                                                              \
+      const uint32_t t_ = __builtin_ctzll(mask_);                                                \
+      mask_ &= mask_ - 1;                                                                        \
+      const uint32_t sa = __builtin_amdgcn_readlane((a), t_);                                    \
+      const uint32_t sb = __builtin_amdgcn_readlane((b), t_);                                    \
+      const uint32_t su_ = slice_units(sa, sb);                                                  \
+      for (uint32_t j_ = ((wid) - t_) & ((kNW) - 1); j_ < su_; j_ += (kNW)) {                     \
+        const uint32_t c = sa + (j_ * 64 + (lane)) * 8;                                          \
+        UNIT_BODY;                                                                               \
+        ++(k);                                                                                   \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+
+// Head of a window: the first three units of this wave (c == b == 0: no such unit).
+// `more` = the wave owns further units; returns true if the window holds any posting.
+template <int kNW>
+__device__ __forceinline__ bool head_units(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, bool two_slots,
+                                           uint32_t wid, uint32_t lane, bool& more, uint32_t& c0, uint32_t& e0,
+                                           uint32_t& c1, uint32_t& e1, uint32_t& c2, uint32_t& e2) {
+  uint32_t k = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+  BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, {
+    x0 = k == 0 ? c : x0; y0 = k == 0 ? sb : y0;
+    x1 = k == 1 ? c : x1; y1 = k == 1 ? sb : y1;
+    x2 = k == 2 ? c : x2; y2 = k == 2 ? sb : y2;
+  });
+  if (two_slots) {
+    BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, {
+      x0 = k == 0 ? c : x0; y0 = k == 0 ? sb : y0;
+      x1 = k == 1 ? c : x1; y1 = k == 1 ? sb : y1;
+      x2 = k == 2 ? c : x2; y2 = k == 2 ? sb : y2;
+    });
+  }
+  c0 = x0; e0 = y0; c1 = x1; e1 = y1; c2 = x2; e2 = y2;
+  more = k > 3;
+  return (__ballot(b0 > a0) | __ballot(b1 > a1)) != 0;
+}
+
+// Units of this wave beyond the first `skip`: loaded and counted in place.
+template <typename CT, int kNW>
+__device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32, uint32_t a0, uint32_t b0,
+                                           uint32_t a1, uint32_t b1, bool two_slots, uint32_t wid,
+                                           uint32_t lane, uint32_t skip) {
+  uint32_t k = 0;
+  BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, { if (k >= skip) bump8<CT>(cnt32, load_group(ent, c, sb)); });
+  if (two_slots)
+    BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, { if (k >= skip) bump8<CT>(cnt32, load_group(ent, c, sb)); });
+}
+
+// Software-pipelined sweep: every wave keeps the needle's slice tables of windows w and w+1 in
+// registers and, while window w is scanned, already has its first three units of window w+1
+// in flight.  A window costs two barriers and, in steady state, no exposed global-memory
+// round trip.
+template <typename CT, int NT>
+__device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
+                                unsigned long long* pool, Control* ctl) {
+  constexpr uint32_t kNW = NT / 64;
+  constexpr uint32_t kPre = 3;                                  // units loaded one window ahead
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t tc = nd.T;                                     // <= 128
+  const uint32_t nwin = A.n_windows;
+  const bool two_slots = tc > 64;
+
+  const bool own0 = lane < tc, own1 = lane + 64 < tc;
+  const uint32_t code0 = own0 ? codes[lane] : 0u;
+  const uint32_t code1 = own1 ? codes[lane + 64] : 0u;
+  // slice tables of window w (ca*/cb*) and w+1 (na*/nb*), plain registers
+  uint32_t ca0 = 0, cb0 = 0, ca1 = 0, cb1 = 0, na0 = 0, nb0 = 0, na1 = 0, nb1 = 0;
+#define BLURRILY_FETCH_TABLE(w_, A0, B0, A1, B1)                                 \
+  do {                                                                           \
+    A0 = B0 = A1 = B1 = 0;                                                       \
+    if ((w_) < nwin) {                                                           \
+      const uint32_t* soff_ = A.slice_off + size_t(w_) * kNumCodes;              \
+      if (own0) { A0 = soff_[code0]; B0 = soff_[code0 + 1]; }                    \
+      if (own1) { A1 = soff_[code1]; B1 = soff_[code1 + 1]; }                    \
+    }                                                                            \
+  } while (0)
+
+  // head of a window: its first kPre units of this wave, loaded ahead of time
+  uint4 u0, u1, u2;
+  bool head_any = false, head_more = false;                     // of the window the head belongs to
+  uint32_t hc0, hb0, hc1, hb1, hc2, hb2;
+#define BLURRILY_LOAD_HEAD(A0, B0, A1, B1)                                                          \
+  do {                                                                                              \
+    head_any = head_units<kNW>(A0, B0, A1, B1, two_slots, wid, lane, head_more, hc0, hb0, hc1, hb1, \
+                               hc2, hb2);                                                           \
+    u0 = load_group(A.ent, hc0, hb0);                                                               \
+    u1 = load_group(A.ent, hc1, hb1);                                                               \
+    u2 = load_group(A.ent, hc2, hb2);                                                               \
+  } while (0)
+
+  BLURRILY_FETCH_TABLE(0u, ca0, cb0, ca1, cb1);
+  BLURRILY_FETCH_TABLE(1u, na0, nb0, na1, nb1);
+  BLURRILY_LOAD_HEAD(ca0, cb0, ca1, cb1);
+
+  PHASE_DECL;
+  for (uint32_t w = 0; w < nwin; ++w) {
+    const uint32_t wbase = w * kWindowRanks;
+    const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+    const bool any = head_any, more = head_more;
+    PHASE_MARK(0);                                              // loop overhead
+    if (any) {
+      // ---- count window w: its head was loaded one window ago ---------------------------
+      bump8<CT>(cnt32, u0);
+      bump8<CT>(cnt32, u1);
+      bump8<CT>(cnt32, u2);
+      PHASE_MARK(1);                                            // head counted
+      if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre);
+      PHASE_MARK(2);                                            // rest counted
+      __syncthreads();                                          // counts visible
+      PHASE_MARK(3);                                            // barrier after count
+    }
+    // keep the memory pipe busy during the scan: head of window w+1 (nxt is all-empty past the end)
+    BLURRILY_LOAD_HEAD(na0, nb0, na1, nb1);
+    PHASE_MARK(4);                                              // next head issued
+    if (any) {
+      for (;;) {
+        scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
+        PHASE_MARK(5);                                          // scan
+        __syncthreads();                                        // counters are zero again
+        PHASE_MARK(6);                                          // barrier after scan
+        if (!select_after_scan<NT>(A, pool, ctl, wbase)) break;
+        count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u);   // overflow: again
+        __syncthreads();
+      }
+      PHASE_MARK(7);                                            // select / compaction
+    }
+    ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
+    BLURRILY_FETCH_TABLE(w + 2, na0, nb0, na1, nb1);
+  }
+  PHASE_FLUSH(A);
+#undef BLURRILY_LOAD_HEAD
+#undef BLURRILY_FETCH_TABLE
+}
+
+template <typename CT, int NT>
+__global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // carve: counters | pool_hi | pool_rk | slice bounds | control
+  // carve: counters | candidate pool | slice table (long needles) | control
   uint32_t* cnt32 = reinterpret_cast<uint32_t*>(smem);
   uint4*    cnt128 = reinterpret_cast<uint4*>(smem);
   constexpr uint32_t kCntBytes = kWindowSize * sizeof(CT);
-  unsigned long long* pool_hi = reinterpret_cast<unsigned long long*>(smem + kCntBytes);
-  uint32_t* pool_rk = reinterpret_cast<uint32_t*>(smem + kCntBytes + size_t(A.pool_cap) * 8);
-  uint32_t* s_a = pool_rk + A.pool_cap;
-  uint32_t* s_b = s_a + kCodeChunk;
-  Control*  ctl = reinterpret_cast<Control*>(s_b + kCodeChunk);
+  unsigned long long* pool = reinterpret_cast<unsigned long long*>(smem + kCntBytes);
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(pool + A.pool_cap);   // [2][kCodeChunk], long needles only
+  Control*  ctl = reinterpret_cast<Control*>(s_tab + 2 * kCodeChunk);
 
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t tid = threadIdx.x;
 
   for (uint32_t i = tid; i < kCntBytes / 16; i += NT) cnt128[i] = make_uint4(0, 0, 0, 0);
-  if (tid == 0) { ctl->nonempty[0] = ctl->nonempty[1] = ctl->nonempty[2] = 0; }
   __syncthreads();
 
   const uint32_t n_work = A.n_work_dev ? *A.n_work_dev : A.n_work;
-  uint32_t step = 0;                                   // rotates the three `nonempty` flags
 
   for (;;) {
     if (tid == 0) ctl->q = atomicAdd(A.queue, 1u);
@@ -230,8 +539,9 @@ __global__ __launch_bounds__(NT) void find_kernel(const FindArgs A) {
     __syncthreads();                                   // everyone has read q before it is rewritten
     if (slot >= n_work) break;
     const uint32_t q = A.work_list ? A.work_list[slot] : slot;
-    const uint32_t T = A.q_ntri[q];
-    if (!A.work_list && T > 127) continue;             // long needles go to the uint16_t launch
+    Needle nd;
+    nd.T = A.q_ntri[q];
+    if (!A.work_list && nd.T > 127) continue;          // long needles go to the uint16_t launch
     const uint32_t have = A.pass_base ? A.counts[q] : 0u;
     if (A.q_nb[q] == 0 || A.keep == 0 || have < A.pass_base) {
       if (tid == 0 && A.pass_base == 0) A.counts[q] = 0;
@@ -239,139 +549,44 @@ __global__ __launch_bounds__(NT) void find_kernel(const FindArgs A) {
     }
     const uint16_t* codes = A.qcodes + A.offsets[q] + q;
     // results after this key only (later passes of a limit larger than the pool)
-    const bool has_floor = A.pass_base != 0;
-    const unsigned long long fl_hi = has_floor ? A.floor_hi[q] : 0ull;
-    const uint32_t fl_rk = has_floor ? A.floor_rk[q] : 0u;
+    nd.has_floor = A.pass_base != 0;
 
-    if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr_hi = kKeyInf; ctl->thr_rk = 0xFFFFFFFFu; }
+    if (tid == 0) {
+      ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf;
+      if (nd.has_floor) ctl->floor = A.floor[q];
+    }
     __syncthreads();
 
-    for (uint32_t w = 0; w < A.n_windows; ++w) {
-      const uint32_t wbase = w << kWindowBits;
-      const uint32_t wlen = min(kWindowSize, A.n_refs - wbase);
-      const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
-      bool redo;
-      do {
-        redo = false;
-        // ---- count: stream the needle's slices of this window ---------------
-        bool touched = false;
-        for (uint32_t c0 = 0; c0 < T; c0 += kCodeChunk) {
-          const uint32_t tc = min(kCodeChunk, T - c0);
-          const uint32_t fl = step % 3;                         // rotating flag, see DESIGN.md
-          ++step;
-          if (tid == 0) ctl->nonempty[(fl + 1) % 3] = 0;
-          if (tid < tc) {
-            const uint32_t code = codes[c0 + tid];
-            const uint32_t a = soff[code], b = soff[code + 1];
-            s_a[tid] = a; s_b[tid] = b;
-            if (b > a) ctl->nonempty[fl] = 1;
-          }
-          __syncthreads();
-          if (ctl->nonempty[fl]) {
-            touched = true;
-            for (uint32_t t = wid; t < tc; t += kNW) {
-              const uint32_t a = __builtin_amdgcn_readfirstlane(s_a[t]);
-              const uint32_t b = __builtin_amdgcn_readfirstlane(s_b[t]);
-              if (a == b) continue;
-              uint32_t c = (a & ~7u) + lane * 8;
-              for (; c + 512 < b; c += 1024) {                  // two 16-byte loads in flight
-                const uint4 v0 = *reinterpret_cast<const uint4*>(A.ent + c);
-                const uint4 v1 = *reinterpret_cast<const uint4*>(A.ent + c + 512);
-                bump8<CT>(cnt32, v0, c, a, b);
-                bump8<CT>(cnt32, v1, c + 512, a, b);
-              }
-              if (c < b) {
-                const uint4 v0 = *reinterpret_cast<const uint4*>(A.ent + c);
-                bump8<CT>(cnt32, v0, c, a, b);
-              }
-            }
-            __syncthreads();                                    // counts visible; s_a/s_b reusable
-          }
-        }
-        if (!touched) break;                                    // nothing of this needle in the window
-
-        // ---- scan: admit counters that can still reach the top `keep` -------
-        const unsigned long long thr_hi = ctl->thr_hi;
-        const uint32_t thr_rk = ctl->thr_rk;
-        // counters below `need` cannot beat the current keep-th candidate
-        const uint32_t need = (thr_hi == kKeyInf) ? 1u : max(1u, T - uint32_t(thr_hi >> 32));
-        const uint32_t bias = (P::kTop - need) * P::kOnes;
-        const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
-        for (uint32_t i = tid; i < nvec; i += NT) {
-          const uint4 v = cnt128[i];
-          if ((v.x | v.y | v.z | v.w) == 0) continue;
-          cnt128[i] = make_uint4(0, 0, 0, 0);
-          const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            uint32_t m = (wv[j] + bias) & P::kHi;
-            while (m) {
-              const uint32_t bit = __ffs(m) - 1;
-              m &= m - 1;
-              const uint32_t pos = bit / P::kBits;
-              const uint32_t cnt = (wv[j] >> (pos * P::kBits)) & P::kMask;
-              const uint32_t rank = wbase + (i * 4 + j) * P::kPerWord + pos;
-              const uint32_t wgt = A.weight_of_rank[rank];
-              const unsigned long long hi = (static_cast<unsigned long long>(T - cnt) << 32) | wgt;
-              bool pass = (hi < thr_hi) || (hi == thr_hi && rank <= thr_rk);
-              if (has_floor) pass = pass && ((hi > fl_hi) || (hi == fl_hi && rank > fl_rk));
-              if (pass) {
-                const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
-                if (at < A.pool_cap) { pool_hi[at] = hi; pool_rk[at] = rank; }
-                else ctl->overflow = 1;
-              }
-            }
-          }
-        }
-        __syncthreads();
-
-        // ---- select: keep the pool small and the threshold tight ------------
-        const uint32_t ov = ctl->overflow;
-        const uint32_t pn = ctl->pool_n;
-        if (ov || pn > A.pool_cap / 2) {
-          compact_pool<NT>(pool_hi, pool_rk, ctl, A.pool_cap, A.keep);
-          if (ov) {
-            // The pool overflowed mid-window: candidates of this window were
-            // lost.  Keep the tightened threshold (it is the keep-th best of a
-            // subset, hence a valid bound), forget this window's survivors and
-            // sweep the window again.
-            if (tid == 0) {
-              uint32_t j = 0;
-              const uint32_t n = ctl->pool_n;
-              for (uint32_t i = 0; i < n; ++i)
-                if (pool_rk[i] < wbase) { pool_hi[j] = pool_hi[i]; pool_rk[j] = pool_rk[i]; ++j; }
-              ctl->pool_n = j;
-            }
-            __syncthreads();
-            redo = true;
-          }
-        }
-      } while (redo);
+    if constexpr (sizeof(CT) == 1) {                 // byte counters: T <= 127 by construction
+      sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl);
+    } else {
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl);
+      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl);
     }
 
-    // ---- emit: best `keep` in final order -----------------------------------
-    compact_pool<NT>(pool_hi, pool_rk, ctl, A.pool_cap, A.keep);
+    // ---- emit: best `keep` in final order; weights are looked up only here ---------------
+    compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
     const uint32_t nres = ctl->pool_n;
     trigram_match_t* out = A.results + size_t(q) * A.limit + A.pass_base;
     for (uint32_t i = tid; i < nres; i += NT) {
-      const unsigned long long hi = pool_hi[i];
-      const uint32_t rk = pool_rk[i];
+      const unsigned long long key = pool[i];
+      const uint32_t rk = uint32_t(key);
       trigram_match_t r;
       r.reference = A.ref_of_rank[rk];
-      r.matches = T - uint32_t(hi >> 32);
-      r.weight = uint32_t(hi);
+      r.matches = nd.T - uint32_t(key >> 32);
+      r.weight = A.weight_of_rank[rk];
       out[i] = r;
     }
     if (tid == 0) {
       A.counts[q] = A.pass_base + nres;
-      if (A.floor_hi && nres > 0) { A.floor_hi[q] = pool_hi[nres - 1]; A.floor_rk[q] = pool_rk[nres - 1]; }
+      if (A.floor && nres > 0) A.floor[q] = pool[nres - 1];
     }
     __syncthreads();                                   // pool reads done before the next needle resets it
   }
 }
 
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
-  return size_t(kWindowSize) * counter_bytes + size_t(pool_cap) * 12 + 2 * kCodeChunk * 4 + sizeof(Control) + 16;
+  return size_t(kWindowSize) * counter_bytes + size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + sizeof(Control) + 16;
 }
 
 }  // namespace
@@ -404,30 +619,41 @@ uint32_t find_pool_cap(uint32_t keep) {
   return cap;
 }
 
-int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
-  constexpr int NT = 256;
-  if (grid == 0) return 0;
-  if (!long_needles) {
-    const size_t lds = find_lds_bytes(1, a.pool_cap);
-    static bool attr_done = false;
-    if (!attr_done) {
-      BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<uint8_t, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
-    }
-    hipLaunchKernelGGL((find_kernel<uint8_t, NT>), dim3(grid), dim3(NT), lds, stream, a);
-  } else {
-    const size_t lds = find_lds_bytes(2, a.pool_cap);
-    static bool attr_done = false;
-    if (!attr_done) {
-      BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<uint16_t, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
-    }
-    hipLaunchKernelGGL((find_kernel<uint16_t, NT>), dim3(grid), dim3(NT), lds, stream, a);
+template <typename CT, int NT>
+static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
+  const size_t lds = find_lds_bytes(sizeof(CT), a.pool_cap);
+  static bool attr_done = false;
+  if (!attr_done) {
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
   }
+  hipLaunchKernelGGL((find_kernel<CT, NT>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int find_threads() {
+  static int nt = 0;
+  if (!nt) {
+    const char* e = std::getenv("BLURRILY_FIND_THREADS");
+    nt = e ? std::atoi(e) : 1024;
+    if (nt != 256 && nt != 512 && nt != 1024) nt = 1024;
+  }
+  return nt;
+}
+
+int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
+  if (grid == 0) return 0;
+  const int nt = find_threads();
+  if (!long_needles) {
+    if (nt == 256) return launch_find_t<uint8_t, 256>(a, grid, stream);
+    if (nt == 512) return launch_find_t<uint8_t, 512>(a, grid, stream);
+    return launch_find_t<uint8_t, 1024>(a, grid, stream);
+  }
+  if (nt == 256) return launch_find_t<uint16_t, 256>(a, grid, stream);
+  if (nt == 512) return launch_find_t<uint16_t, 512>(a, grid, stream);
+  return launch_find_t<uint16_t, 1024>(a, grid, stream);
 }
 
 }  // namespace blurrily

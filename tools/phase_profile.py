@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the find kernel (profiling build: make -C blurrily_amd/csrc profile).
+
+Usage on the GPU box:
+    BLURRILY_LIB=blurrily_amd/libblurrily_hip_prof.so python tools/phase_profile.py [scale] [n_queries]
+Prints shader clocks per window per phase as seen by wave 0 of each workgroup.
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+import numpy as np  # noqa: E402
+import workloads as W  # noqa: E402
+from blurrily_amd import RawMap, _native  # noqa: E402
+
+PHASES = ["loop/table", "count prefetched", "count rest", "barrier(count)", "issue next head", "scan",
+          "barrier(scan)", "select"]
+
+
+def main():
+    scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    nq = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+    n = int(8423769 * scale)
+    hay, off = W.geonames(n, max(1000, int(500000 * min(1.0, scale * 4))), 3)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    m.sync_device()
+    info = m.device_info()
+    lib = _native.lib()
+    lib.blurrily_debug_phase_clocks.argtypes = [C.c_void_p, C.c_size_t]
+    for batch in (1, nq):
+        qp, qo = W.queries(hay, off, batch, 3000)
+        t = time.perf_counter()
+        rows, counts = m.find_batch_packed(qp, qo, 10)
+        dt = time.perf_counter() - t
+        nwg = min(batch, 512)
+        buf = np.zeros((nwg, 8), dtype=np.uint64)
+        assert lib.blurrily_debug_phase_clocks(buf.ctypes.data, nwg) == 0
+        tot = buf.sum(axis=0).astype(np.float64)
+        per_window = tot / (batch * info["n_windows"])
+        print(f"batch {batch}: {dt * 1e3:.2f} ms wall, {info['n_windows']} windows; clocks per (query, window):")
+        for name, v in zip(PHASES, per_window):
+            print(f"   {name:18s} {v:9.0f}")
+        print(f"   {'TOTAL':18s} {per_window.sum():9.0f}")
+
+
+if __name__ == "__main__":
+    main()
