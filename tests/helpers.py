@@ -154,3 +154,35 @@ def build_pair(strings, refs=None, weights=None):
         b = o.put(s, r, w)
         assert a == b, (s, r, w, a, b)
     return m, o
+
+
+def golden_haystack(h):
+    """Rebuild the seeded haystack a tests/golden/ref_find_*.json fixture was generated from:
+    returns (packed, offsets, refs uint32[n], weights uint32[n] or None).  Shared by
+    tools/make_golden.py so generator and tests cannot drift apart."""
+    import workloads as W
+    n = h["n"]
+    if h["kind"] == "words":
+        hay, off = W.words(n, h["seed"])
+    elif h["kind"] == "geonames":
+        hay, off = W.geonames(n, max(500, n // 10), h["seed"])
+    else:
+        hay, off = W.skewed(n, h["seed"])
+    rng = np.random.default_rng(h["ref_seed"])
+    refs = np.arange(1, n + 1, dtype=np.uint32)
+    if h["refs"] == "sparse":
+        refs = (rng.choice(2**31 - 2, size=n, replace=False) + 1).astype(np.uint32)
+    weights = None
+    if h["weights"] == "small":
+        weights = rng.integers(0, 4, size=n).astype(np.uint32)
+    return hay, off, refs, weights
+
+
+def load_golden(name):
+    import json
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def golden_find_files():
+    return sorted(f for f in os.listdir(GOLDEN) if f.startswith("ref_find_") and f.endswith(".json"))

@@ -1,0 +1,90 @@
+"""GPU parity against data produced by the reference's own C: the committed fixtures
+(tests/golden/ref_find_*.json) and, where oracle/_ref travelled with the snapshot, the live
+reference on larger haystacks; plus size-independent properties at BASELINE.json's full
+Geonames scale, with a sample checked row for row against the oracle."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import workloads as W
+from blurrily_amd import RawMap
+from helpers import Oracle, Reference, golden_find_files, golden_haystack, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(m, needles, limit):
+    packed = np.frombuffer(b"".join(needles), dtype=np.uint8)
+    off = np.zeros(len(needles) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in needles])
+    rows, counts = m.find_batch_packed(packed, off, limit)
+    return [rows[i, :counts[i]].tolist() for i in range(len(needles))]
+
+
+@pytest.mark.parametrize("name", golden_find_files())
+def test_hip_matches_reference_fixture(name):
+    g = load_golden(name)
+    hay, off, refs, weights = golden_haystack(g["haystack"])
+    m = RawMap()
+    m.put_many_packed(hay, off, refs, weights)
+    assert m.stats() == g["stats"]
+    needles = [bytes.fromhex(h) for h in g["needles_hex"]]
+    assert _batch(m, needles, g["limit"]) == g["expected"]
+    for nd, want in list(zip(needles, g["expected"]))[:10]:           # the single-needle entry point too
+        rows = (np.zeros((g["limit"], 3), dtype=np.uint32))
+        n = m._lib.blurrily_storage_find(m.handle, nd, g["limit"], rows.ctypes.data)
+        assert rows[:n].tolist() == want
+
+
+@pytest.mark.skipif(not Reference.available(), reason="oracle/_ref did not travel with the snapshot")
+@pytest.mark.parametrize("kind,n,limit", [("geonames", 300000, 10), ("skewed", 200000, 100), ("words", 235886, 10)])
+def test_hip_vs_live_reference(kind, n, limit):
+    hay, off = {"words": W.words, "skewed": W.skewed}.get(kind, lambda n, s: W.geonames(n, 30000, s))(n, 17)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    q, qo = W.queries(hay, off, 300, 18)
+    needles = W.unpack(q, qo)
+    got = _batch(m, needles, limit)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "h.trigrams")
+        m.save(path)
+        ref = Reference(path)
+        for nd, rows in zip(needles, got):
+            assert rows == ref.find(nd, limit), nd
+        ref.close()
+
+
+def test_full_geonames_scale_properties():
+    """configs[2] haystack (8 423 769 strings): properties that need no full-size checker, and a
+    sample of needles checked row for row against the oracle."""
+    n = 8423769
+    hay, off = W.geonames(n, 500000, 3)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    rng = np.random.default_rng(1)
+    picks = rng.integers(0, n, size=2000)
+    strings = [hay[int(off[i]):int(off[i + 1])].tobytes() for i in picks]
+    q, qo = W.queries(hay, off, 2000, 99)
+    needles = strings + W.unpack(q, qo)
+    limit = 10
+    got = _batch(m, needles, limit)
+    again = _batch(m, needles, limit)
+    assert got == again                                            # idempotent
+    for nd, rows in zip(needles, got):
+        T = len(Oracle.tokenise(nd))
+        assert len(rows) <= limit
+        keys = [(-r[1], r[2], r[0]) for r in rows]
+        assert keys == sorted(keys) and len(set(r[0] for r in rows)) == len(rows)   # the total order, no dup refs
+        assert all(1 <= r[1] <= T for r in rows)
+    for i, (nd, rows) in enumerate(zip(strings, got)):             # an indexed string finds itself
+        T = len(Oracle.tokenise(nd))
+        assert rows[0][1] == T and rows[0][2] == len(nd)
+        full = [r[0] for r in rows if r[1] == T and r[2] == len(nd)]
+        ref_id = int(picks[i]) + 1
+        assert ref_id in full or (len(full) == limit and ref_id > max(full))
+    o = Oracle()
+    o.put_many(hay, off)
+    for nd, rows in list(zip(needles, got))[1990:2030]:
+        assert rows == o.find(nd, limit), nd

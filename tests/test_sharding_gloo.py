@@ -1,0 +1,77 @@
+"""The N>1 path on CPU: world_size 2 over gloo.  The shard/gather code of
+blurrily_amd/sharding.py is exercised with the oracle standing in for the per-rank GPU find
+(the HIP path itself is covered by the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from blurrily_amd.sharding import shard_bounds
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 9, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_needles, limit, out_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tools"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import workloads as W
+    from helpers import Oracle
+    from blurrily_amd.sharding import find_batch_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hay, off = W.words(3000, 5)                       # index replicated on every rank
+    o = Oracle()
+    o.put_many(hay, off)
+    q, qo = W.queries(hay, off, n_needles, 6)
+    needles = W.unpack(q, qo)
+
+    def find_fn(batch, lim):                           # stand-in for the per-rank GPU batch
+        rows = torch.zeros((len(batch), lim, 3), dtype=torch.int32)
+        counts = torch.zeros((len(batch),), dtype=torch.int32)
+        for i, nd in enumerate(batch):
+            r = o.find(nd, lim)
+            counts[i] = len(r)
+            if r:
+                rows[i, :len(r)] = torch.tensor(r, dtype=torch.int64).to(torch.int32)
+        return rows, counts
+
+    got = find_batch_sharded(dist, find_fn, needles, limit, rank, world)
+    if rank == 0:
+        rows, counts = got
+        ok = rows.shape[0] == n_needles
+        for i, nd in enumerate(needles):
+            want = o.find(nd, limit)
+            ok = ok and rows[i, :int(counts[i])].tolist() == want
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_needles", [64, 37])       # even split, and a ragged last shard
+def test_world_size_2_gather_reassembles_in_order(tmp_path, n_needles):
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(2, _free_port(), n_needles, 5, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
