@@ -231,6 +231,11 @@ def main():
             lib.blurrily_storage_find(m.handle, nd, limit, rows)
             lat.append(time.perf_counter() - t)
         p50_us = float(np.median(lat) * 1e6) if lat else None
+        # the same batch through the host-buffer entry point: H2D of the needles and D2H of the
+        # result rows included (reported beside `value`, never as `value`)
+        t = time.perf_counter()
+        m.find_batch_packed(qp, qo, limit)
+        host_rate = n_q / (time.perf_counter() - t)
         info = m.device_info()
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -252,11 +257,13 @@ def main():
                        "index_replicated": world > 1, "parallelism": f"query-shard x{world}",
                        "scale": args.scale},
             "p50_query_us": p50_us,
+            "host_buffer_queries_per_sec": host_rate,
             "matched_entries_per_sec": total_entries * args.steps / elapsed,
             "entries_per_query": sum_nb / n_q,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "find_kernel<uint8_t,256>", "kernel_ms": k_ms,
+                         "kernel": "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024"),
+                         "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "resident_index_bytes": int(info["device_bytes"])},
         }

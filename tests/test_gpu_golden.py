@@ -80,10 +80,10 @@ def test_full_geonames_scale_properties():
         assert all(1 <= r[1] <= T for r in rows)
     for i, (nd, rows) in enumerate(zip(strings, got)):             # an indexed string finds itself
         T = len(Oracle.tokenise(nd))
-        assert rows[0][1] == T and rows[0][2] == len(nd)
-        full = [r[0] for r in rows if r[1] == T and r[2] == len(nd)]
-        ref_id = int(picks[i]) + 1
-        assert ref_id in full or (len(full) == limit and ref_id > max(full))
+        own = (-T, len(nd), int(picks[i]) + 1)                     # all trigrams match; weight = strlen
+        keys = [(-r[1], r[2], r[0]) for r in rows]
+        assert rows[0][1] == T                                     # nothing can match more than T trigrams
+        assert own in keys or (len(keys) == limit and max(keys) < own)
     o = Oracle()
     o.put_many(hay, off)
     for nd, rows in list(zip(needles, got))[1990:2030]:
