@@ -54,7 +54,7 @@ struct trigram_map_t {
   bool        timing = false;
   double      last_find_ms = 0.0, last_tok_ms = 0.0;
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  DeviceBuffer ws_codes, ws_small, ws_io_packed, ws_io_offsets, ws_io_results, ws_io_counts;
+  DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_packed, ws_io_offsets, ws_io_results, ws_io_counts;
 };
 
 namespace {
@@ -76,10 +76,23 @@ int ensure_device(trigram_map m) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// BLURRILY_FIND_MODE=block opts into the experimental block sweep (find_block_kernel: a
+// workgroup sweeps a block of needles window-major).  Measured on MI355X it matches the
+// default one-needle-per-workgroup sweep (755 k vs 747 k needles/s): the
+// step is bound by LDS atomics and scan, not by global loads, so it is not the default.
+bool use_block_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = std::getenv("BLURRILY_FIND_MODE");
+    mode = (e && std::strcmp(e, "block") == 0) ? 1 : 0;
+  }
+  return mode == 1;
+}
+
 // Enqueue tokenise + find for n device-resident needles.
 int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
              uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long,
-             hipStream_t stream) {
+             bool maybe_mid, hipStream_t stream) {
   if (n == 0) return 0;
   if (n > 0xFFFFFFF0ull) { errno = EINVAL; return -1; }
   const DeviceIndex& ix = m->dev;
@@ -89,13 +102,14 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   if (m->ws_codes.reserve(align_up(code_slots * sizeof(uint16_t), 256), stream) < 0) return -1;
   const size_t per_n = align_up(n * sizeof(uint32_t), 256);
   const bool multi_pass = limit > 256;             // long needles keep 256 rows per pass, short ones 1024
-  const size_t small_bytes = per_n * 3 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
+  const size_t small_bytes = per_n * 4 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
   if (m->ws_small.reserve(small_bytes, stream) < 0) return -1;
   unsigned char* sp = static_cast<unsigned char*>(m->ws_small.p);
-  uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1..]=queues
+  uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1]=mid_count [2..]=queues
   uint32_t* q_ntri   = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* q_nb_ws  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* big_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
+  uint32_t* mid_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   unsigned long long* floor = nullptr;
   if (multi_pass) floor = reinterpret_cast<unsigned long long*>(sp);
   uint32_t* q_nb = d_nb ? d_nb : q_nb_ws;
@@ -103,7 +117,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
 
   if (m->timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev[0], stream));
   TokeniseArgs t{d_packed, d_offsets, uint32_t(n), ix.d_code_total, static_cast<uint16_t*>(m->ws_codes.p),
-                 q_ntri, q_nb, big_list, scalars};
+                 q_ntri, q_nb, big_list, scalars, mid_list, scalars + 1};
   if (launch_tokenise(t, stream) < 0) return -1;
   if (m->timing) {
     BLURRILY_HIP_TRY(hipEventRecord(m->ev[1], stream));
@@ -125,12 +139,12 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
     g_phase_clocks = d_phase;
   }
 #endif
-  // every launch gets its own zeroed queue word (scalars[1..63]); recycled in stream order
-  uint32_t queue_slot = 1;
+  // every launch gets its own zeroed queue word (scalars[2..63]); recycled in stream order
+  uint32_t queue_slot = 2;
   auto next_queue = [&]() -> uint32_t* {
     if (queue_slot >= 64) {
-      if (hipMemsetAsync(scalars + 1, 0, 252, stream) != hipSuccess) return nullptr;
-      queue_slot = 1;
+      if (hipMemsetAsync(scalars + 2, 0, 248, stream) != hipSuccess) return nullptr;
+      queue_slot = 2;
     }
     return scalars + queue_slot++;
   };
@@ -138,13 +152,61 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   if (limit == 0) {
     BLURRILY_HIP_TRY(hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), stream));
   } else {
+    // Block mode: small limits sweep blocks of needles window-major (L2 reuse); it owns the
+    // needles with <= 64 distinct trigrams, the 65..127 ones follow through find_kernel.
+    uint32_t mini_cap = 0;
+    uint32_t block = use_block_mode() ? find_block_size(limit, &mini_cap) : 0;
+    if (block) {
+      // at least ~4 blocks per resident workgroup so the tail stays short on small batches
+      const size_t wgs = size_t(m->n_cus) * 2;
+      while (block > 1 && (n + block - 1) / block < wgs * 4) block = (block + 1) / 2;
+      a.work_list = nullptr; a.n_work_dev = nullptr;
+      a.block_size = block; a.n_needles = uint32_t(n); a.n_work = uint32_t((n + block - 1) / block);
+      a.pass_base = 0; a.keep = limit; a.pool_cap = mini_cap;
+      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+      if (launch_find_block(a, uint32_t(std::min<size_t>(a.n_work, wgs)), stream) < 0) return -1;
+      if (maybe_mid) {
+        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+        a.pool_cap = find_pool_cap(a.keep);
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        if (launch_find(a, false, uint32_t(std::min<size_t>(n, size_t(m->n_cus))), stream) < 0) return -1;
+      }
+    }
+    // Latency mode: a batch too small to fill the GPU cuts every needle's windows into ranges
+    // swept by different workgroups, then merges the per-range candidates (single pass only).
+    const size_t wgs = size_t(m->n_cus) * 2;
+    uint32_t ranges = 1;
+    if (!block && limit <= 1024 && n < wgs / 2 && ix.n_windows > 1) {
+      ranges = uint32_t(std::min<size_t>(ix.n_windows, (2 * wgs) / n));
+      ranges = std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit));     // merge pool
+    }
+    if (ranges > 1) {
+      const size_t tasks = n * ranges;
+      const size_t key_bytes = align_up(tasks * limit * 8, 256);
+      if (m->ws_parts.reserve(key_bytes + align_up(tasks * 4, 256), stream) < 0) return -1;
+      a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(tasks);
+      a.ranges = ranges;
+      a.part_keys = static_cast<unsigned long long*>(m->ws_parts.p);
+      a.part_count = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(m->ws_parts.p) + key_bytes);
+      a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
+      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+      // needles with > 127 distinct trigrams are skipped by the byte-counter kernel: their
+      // tasks must not leave stale counts behind for the merge
+      BLURRILY_HIP_TRY(hipMemsetAsync(a.part_count, 0, tasks * 4, stream));
+      if (launch_find(a, false, uint32_t(std::min<size_t>(tasks, wgs)), stream) < 0) return -1;
+      uint32_t merge_cap = 1024;
+      while (merge_cap < ranges * limit) merge_cap <<= 1;
+      a.pool_cap = merge_cap;
+      if (launch_merge_parts(a, uint32_t(n), stream) < 0) return -1;
+      a.ranges = 0; a.part_keys = nullptr; a.part_count = nullptr;
+    }
     // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
-    for (uint32_t base = 0; base < limit; base += 1024) {
+    for (uint32_t base = 0; !block && ranges <= 1 && base < limit; base += 1024) {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = base; a.keep = std::min<uint32_t>(1024, limit - base);
       a.pool_cap = find_pool_cap(a.keep);
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-      const uint32_t grid = uint32_t(std::min<size_t>(n, size_t(m->n_cus) * 2));
+      const uint32_t grid = uint32_t(std::min<size_t>(n, wgs));
       if (launch_find(a, false, grid, stream) < 0) return -1;
     }
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
@@ -200,7 +262,7 @@ int blurrily_storage_close(trigram_map* haystack) {
       device_index_free(&m->dev);
     }
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
-    m->ws_codes.release(); m->ws_small.release(); m->ws_io_packed.release();
+    m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_packed.release();
     m->ws_io_offsets.release(); m->ws_io_results.release(); m->ws_io_counts.release();
     delete m->host;
     delete m;
@@ -255,7 +317,7 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
   if (m->timing && !m->ev[0])
     for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
   return run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_results, d_counts, d_nb_entries, true,
-                  static_cast<hipStream_t>(stream));
+                  true, static_cast<hipStream_t>(stream));
 }
 
 int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_t* offsets, size_t n,
@@ -295,7 +357,7 @@ int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_
   if (run_find(m, static_cast<const char*>(m->ws_io_packed.p), packed_bytes,
                static_cast<const uint64_t*>(m->ws_io_offsets.p), n, limit,
                static_cast<trigram_match>(m->ws_io_results.p), static_cast<uint32_t*>(m->ws_io_counts.p),
-               nullptr, max_len > 126, stream) < 0)
+               nullptr, max_len > 126, max_len > 63, stream) < 0)
     return -1;
   BLURRILY_HIP_TRY(hipMemcpyAsync(counts, m->ws_io_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if (limit)

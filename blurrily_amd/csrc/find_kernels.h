@@ -20,6 +20,8 @@ struct TokeniseArgs {
   uint32_t*       q_nb;        // [n] nb_entries per needle (storage.c:498-502)
   uint32_t*       big_list;    // [n] needles with > 127 distinct trigrams
   uint32_t*       big_count;   // [1]
+  uint32_t*       mid_list;    // [n] needles with 65..127 distinct trigrams
+  uint32_t*       mid_count;   // [1]
 };
 
 struct FindArgs {
@@ -45,8 +47,14 @@ struct FindArgs {
   uint32_t        limit;       // row stride
   uint32_t        keep;        // rows wanted from this pass
   uint32_t        pass_base;   // rows already delivered by earlier passes
-  uint32_t        pool_cap;    // power of two, >= 4*keep
+  uint32_t        pool_cap;    // power of two, >= 4*keep (block mode: keys per mini-pool)
+  uint32_t        block_size;  // block mode: needles per workgroup (<= 64)
+  uint32_t        n_needles;   // block mode: needles in the batch (n_work counts blocks)
   unsigned long long* floor;   // [n] last key delivered by the previous pass (multi-pass only)
+  // latency mode (small batches): every needle's windows are cut into `ranges` tasks
+  uint32_t        ranges;      // 0/1: off
+  unsigned long long* part_keys;   // [n_items * ranges * keep] best keys of every task
+  uint32_t*       part_count;  // [n_items * ranges]
   unsigned long long* phase_clocks;  // profiling builds only (make profile), else nullptr
 };
 
@@ -54,5 +62,8 @@ uint32_t find_pool_cap(uint32_t keep);
 int find_threads();   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
+uint32_t find_block_size(uint32_t keep, uint32_t* mini_cap);
+int launch_find_block(const FindArgs& a, uint32_t grid, hipStream_t stream);
+int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
 
 }  // namespace blurrily

@@ -71,7 +71,8 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
                                 uint32_t n, const uint32_t* __restrict__ code_total,
                                 uint16_t* __restrict__ qcodes, uint32_t* __restrict__ q_ntri,
                                 uint32_t* __restrict__ q_nb, uint32_t* __restrict__ big_list,
-                                uint32_t* __restrict__ big_count) {
+                                uint32_t* __restrict__ big_count, uint32_t* __restrict__ mid_list,
+                                uint32_t* __restrict__ mid_count) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const uint64_t beg = offsets[q], end = offsets[q + 1];
@@ -124,7 +125,8 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   }
   q_ntri[q] = d;
   q_nb[q] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
-  if (d > 127) big_list[atomicAdd(big_count, 1u)] = q;
+  if (d > 127) big_list[atomicAdd(big_count, 1u)] = q;            // 16-bit counters
+  else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, but not block mode
 }
 
 // ------------------------------------------------------------- find kernel ---
@@ -218,13 +220,13 @@ struct Needle {
 
 // ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
 template <typename CT, int NT>
-__device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd, uint4* cnt128,
-                                            unsigned long long* pool, Control* ctl, uint32_t wbase,
-                                            uint32_t wlen) {
+__device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
+                                          const unsigned long long* floor, unsigned long long* pool,
+                                          const uint32_t pool_cap, uint32_t* pool_n, uint32_t* overflow,
+                                          uint32_t wbase, uint32_t wlen) {
   using P = Packing<CT>;
   constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
   const uint32_t tid = threadIdx.x;
-  const unsigned long long thr = ctl->thr;
   // A counter must reach `need` to beat the current keep-th candidate: its match count, or one
   // more once the sweep has passed that candidate's rank (ties lose to the lower rank).
   uint32_t need = 1;
@@ -247,11 +249,11 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
           const uint32_t rank = wbase + (i * 4 + j) * P::kPerWord + pos;
           const unsigned long long key = (static_cast<unsigned long long>(nd.T - cnt) << 32) | rank;
           bool pass = key <= thr;
-          if (nd.has_floor) pass = pass && key > ctl->floor;
+          if (nd.has_floor) pass = pass && key > *floor;
           if (pass) {
-            const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
-            if (at < A.pool_cap) pool[at] = key;
-            else ctl->overflow = 1;
+            const uint32_t at = atomicAdd(pool_n, 1u);
+            if (at < pool_cap) pool[at] = key;
+            else *overflow = 1;
           }
         }
       };
@@ -282,6 +284,14 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
   }
   // a short window does not reach the vector holding the padding slot: clear it here
   if (nvec < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+}
+
+template <typename CT, int NT>
+__device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd, uint4* cnt128,
+                                            unsigned long long* pool, Control* ctl, uint32_t wbase,
+                                            uint32_t wlen) {
+  scan_core<CT, NT>(cnt128, nd, ctl->thr, &ctl->floor, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow, wbase,
+                    wlen);
 }
 
 // ---- select: keep the pool small and the threshold tight.  Returns true when the pool
@@ -336,12 +346,13 @@ __device__ __forceinline__ bool count_window(const FindArgs& A, uint32_t* cnt32,
 // Sweep for needles whose trigrams need several staging chunks (> 128 distinct trigrams).
 template <typename CT, int NT>
 __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
-                              unsigned long long* pool, uint32_t* s_tab, Control* ctl) {
+                              unsigned long long* pool, uint32_t* s_tab, Control* ctl, const uint32_t w0,
+                              const uint32_t w1) {
   constexpr uint32_t kNW = NT / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint32_t* s_a = s_tab;
   uint32_t* s_b = s_tab + kCodeChunk;
-  for (uint32_t w = 0; w < A.n_windows; ++w) {
+  for (uint32_t w = w0; w < w1; ++w) {
     const uint32_t wbase = w * kWindowRanks;
     const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
     const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
@@ -434,12 +445,12 @@ __device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32,
 // round trip.
 template <typename CT, int NT>
 __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
-                                unsigned long long* pool, Control* ctl) {
+                                unsigned long long* pool, Control* ctl, const uint32_t w0, const uint32_t w1) {
   constexpr uint32_t kNW = NT / 64;
   constexpr uint32_t kPre = 3;                                  // units loaded one window ahead
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t tc = nd.T;                                     // <= 128
-  const uint32_t nwin = A.n_windows;
+  const uint32_t nwin = w1;                                     // windows [w0, w1) of the rank space
   const bool two_slots = tc > 64;
 
   const bool own0 = lane < tc, own1 = lane + 64 < tc;
@@ -470,12 +481,12 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     u2 = load_group(A.ent, hc2, hb2);                                                               \
   } while (0)
 
-  BLURRILY_FETCH_TABLE(0u, ca0, cb0, ca1, cb1);
-  BLURRILY_FETCH_TABLE(1u, na0, nb0, na1, nb1);
+  BLURRILY_FETCH_TABLE(w0, ca0, cb0, ca1, cb1);
+  BLURRILY_FETCH_TABLE(w0 + 1, na0, nb0, na1, nb1);
   BLURRILY_LOAD_HEAD(ca0, cb0, ca1, cb1);
 
   PHASE_DECL;
-  for (uint32_t w = 0; w < nwin; ++w) {
+  for (uint32_t w = w0; w < nwin; ++w) {
     const uint32_t wbase = w * kWindowRanks;
     const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
     const bool any = head_any, more = head_more;
@@ -514,7 +525,9 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 #undef BLURRILY_FETCH_TABLE
 }
 
-template <typename CT, int NT>
+// RANGED = latency mode (a needle's windows cut into ranges); a separate instantiation so the
+// throughput kernel does not carry the extra live registers.
+template <typename CT, int NT, bool RANGED>
 __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // carve: counters | candidate pool | slice table (long needles) | control
@@ -538,13 +551,20 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     const uint32_t slot = ctl->q;
     __syncthreads();                                   // everyone has read q before it is rewritten
     if (slot >= n_work) break;
-    const uint32_t q = A.work_list ? A.work_list[slot] : slot;
+    // latency mode: a needle's windows are cut into `ranges` tasks swept by different workgroups
+    const uint32_t R = RANGED ? A.ranges : 1u;
+    const uint32_t item = RANGED ? slot / R : slot, range = RANGED ? slot - item * R : 0u;
+    const uint32_t q = A.work_list ? A.work_list[item] : item;
+    const uint32_t w0 = RANGED ? uint32_t(uint64_t(A.n_windows) * range / R) : 0u;
+    const uint32_t w1 = RANGED ? uint32_t(uint64_t(A.n_windows) * (range + 1) / R) : A.n_windows;
     Needle nd;
     nd.T = A.q_ntri[q];
     if (!A.work_list && nd.T > 127) continue;          // long needles go to the uint16_t launch
     const uint32_t have = A.pass_base ? A.counts[q] : 0u;
     if (A.q_nb[q] == 0 || A.keep == 0 || have < A.pass_base) {
-      if (tid == 0 && A.pass_base == 0) A.counts[q] = 0;
+      if (tid == 0 && A.pass_base == 0) {
+        if (RANGED) A.part_count[slot] = 0; else A.counts[q] = 0;
+      }
       continue;
     }
     const uint16_t* codes = A.qcodes + A.offsets[q] + q;
@@ -558,15 +578,22 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     __syncthreads();
 
     if constexpr (sizeof(CT) == 1) {                 // byte counters: T <= 127 by construction
-      sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl);
+      sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, w0, w1);
     } else {
-      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl);
-      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl);
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, w0, w1);
     }
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
     compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
     const uint32_t nres = ctl->pool_n;
+    if (RANGED) {
+      // latency mode: leave this range's best keys for merge_parts_kernel
+      for (uint32_t i = tid; i < nres; i += NT) A.part_keys[size_t(slot) * A.keep + i] = pool[i];
+      if (tid == 0) A.part_count[slot] = nres;
+      __syncthreads();
+      continue;
+    }
     trigram_match_t* out = A.results + size_t(q) * A.limit + A.pass_base;
     for (uint32_t i = tid; i < nres; i += NT) {
       const unsigned long long key = pool[i];
@@ -583,6 +610,260 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     }
     __syncthreads();                                   // pool reads done before the next needle resets it
   }
+}
+
+// ---- latency mode, second half: merge the per-range candidates of every needle -------------
+// One workgroup per needle: the best `keep` of the union of the per-range best `keep` keys is
+// the needle's result (every range keeps its own top `keep`, so nothing can be lost).
+template <int NT>
+__global__ __launch_bounds__(NT) void merge_parts_kernel(const FindArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* pool = reinterpret_cast<unsigned long long*>(smem);
+  Control* ctl = reinterpret_cast<Control*>(pool + A.pool_cap);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t item = blockIdx.x, R = A.ranges;
+  const uint32_t q = A.work_list ? A.work_list[item] : item;
+  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; }
+  __syncthreads();
+  for (uint32_t r = 0; r < R; ++r) {
+    const uint32_t slot = item * R + r;
+    const uint32_t n = A.part_count[slot];
+    if (tid < n) pool[atomicAdd(&ctl->pool_n, 1u)] = A.part_keys[size_t(slot) * A.keep + tid];
+  }
+  __syncthreads();
+  compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+  const uint32_t nres = ctl->pool_n;
+  const uint32_t T = A.q_ntri[q];
+  trigram_match_t* out = A.results + size_t(q) * A.limit;
+  for (uint32_t i = tid; i < nres; i += NT) {
+    const unsigned long long key = pool[i];
+    const uint32_t rk = uint32_t(key);
+    trigram_match_t row;
+    row.reference = A.ref_of_rank[rk];
+    row.matches = T - uint32_t(key >> 32);
+    row.weight = A.weight_of_rank[rk];
+    out[i] = row;
+  }
+  if (tid == 0) A.counts[q] = nres;
+}
+
+// =============================================================================================
+// Block sweep: one workgroup owns a block of up to 64 needles and sweeps window-major -- for
+// each window, for each needle of the block -- so that the hot slices of a window are read
+// once from HBM and then served from L1/L2 to the other needles of the block and to the other
+// workgroups of the XCD, which move through the windows at the same pace.  Per-needle state
+// between windows is a mini-pool of candidate keys and a threshold, both in LDS; pools are
+// sorted by single waves (no workgroup barrier), asynchronously to the sweep.
+// Serves needles with <= 64 distinct trigrams and limits whose mini-pool fits (host decides);
+// everything else goes through find_kernel.
+// =============================================================================================
+
+struct BlockMeta {            // one needle of the block
+  unsigned long long thr;     // admission threshold (kKeyInf: fewer than `keep` candidates so far)
+  uint32_t count;             // keys in the mini-pool (runs past the capacity while overflowing)
+  uint32_t T;                 // distinct trigrams
+  uint32_t q;                 // needle id
+  uint32_t pad;
+};
+
+struct BlockControl {
+  uint32_t slot;
+  uint32_t overflow;
+  uint32_t n_active;
+  uint32_t pad;
+};
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One wave sorts a mini-pool ascending, keeps the best `keep`, tightens the threshold.
+__device__ __forceinline__ void wave_compact(unsigned long long* pool, BlockMeta* m, uint32_t cap, uint32_t keep,
+                                             uint32_t lane) {
+  const uint32_t n = min(m->count, cap);
+  uint32_t P = 1;
+  while (P < n) P <<= 1;
+  for (uint32_t i = n + lane; i < P; i += 64) pool[i] = kKeyInf;
+  wave_sync_lds();
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = lane; i < (P >> 1); i += 64) {
+        const uint32_t lo = 2 * i - (i & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const bool asc = (lo & size) == 0;
+        const unsigned long long x = pool[lo], y = pool[hi];
+        if ((x > y) == asc) { pool[lo] = y; pool[hi] = x; }
+      }
+      wave_sync_lds();
+    }
+  }
+  if (lane == 0) {
+    m->count = min(n, keep);
+    if (n >= keep && keep > 0) m->thr = pool[keep - 1];
+  }
+  wave_sync_lds();
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT, 8) void find_block_kernel(const FindArgs A) {
+  using CT = uint8_t;
+  constexpr uint32_t kNW = NT / 64;
+  constexpr uint32_t kCntBytes = kWindowSize;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // carve: counters | mini-pools | codes | meta | control
+  uint32_t* cnt32 = reinterpret_cast<uint32_t*>(smem);
+  uint4*    cnt128 = reinterpret_cast<uint4*>(smem);
+  const uint32_t B = A.block_size, MP = A.pool_cap;
+  unsigned long long* pools = reinterpret_cast<unsigned long long*>(smem + kCntBytes);
+  uint16_t* s_codes = reinterpret_cast<uint16_t*>(pools + size_t(B) * MP);          // [B][64]
+  BlockMeta* meta = reinterpret_cast<BlockMeta*>(s_codes + size_t(B) * 64);
+  BlockControl* ctl = reinterpret_cast<BlockControl*>(meta + B);
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t nwin = A.n_windows;
+
+  for (uint32_t i = tid; i < kCntBytes / 16; i += NT) cnt128[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  for (;;) {
+    if (tid == 0) ctl->slot = atomicAdd(A.queue, 1u);
+    __syncthreads();
+    const uint32_t slot = ctl->slot;
+    __syncthreads();
+    if (slot >= A.n_work) break;
+
+    // ---- block setup: wave 0 picks the needles this kernel owns and packs the active ones --
+    if (wid == 0) {
+      const uint32_t q = slot * B + lane;
+      const bool valid = lane < B && q < A.n_needles;
+      const uint32_t T = valid ? A.q_ntri[q] : 0u;
+      const bool own = valid && T <= 64;                 // longer needles: find_kernel launches
+      const bool act = own && A.q_nb[q] != 0;
+      if (own && !act) A.counts[q] = 0;
+      const unsigned long long mask = __ballot(act);
+      const uint32_t idx = __popcll(mask & ((1ull << lane) - 1ull));
+      if (act) { meta[idx].thr = kKeyInf; meta[idx].count = 0; meta[idx].T = T; meta[idx].q = q; }
+      if (lane == 0) { ctl->n_active = __popcll(mask); ctl->overflow = 0; }
+    }
+    __syncthreads();
+    const uint32_t Bn = ctl->n_active;
+    if (Bn == 0) continue;
+    for (uint32_t x = tid; x < Bn * 64; x += NT) {
+      const uint32_t idx = x >> 6, j = x & 63;
+      const uint32_t q = meta[idx].q;
+      s_codes[x] = j < meta[idx].T ? A.qcodes[A.offsets[q] + q + j] : uint16_t(0);
+    }
+    __syncthreads();
+
+    // ---- sweep: steps (w, qi), window-major ------------------------------------------------
+    uint32_t fw = 0, fq = 0;                           // step the next table fetch belongs to
+    uint32_t ca = 0, cb = 0, na = 0, nb = 0;           // slice tables of this step / the next step
+#define BLURRILY_FETCH_STEP(A0, B0)                                               \
+  do {                                                                            \
+    A0 = B0 = 0;                                                                  \
+    if (fw < nwin) {                                                              \
+      if (lane < meta[fq].T) {                                                    \
+        const uint32_t code_ = s_codes[fq * 64 + lane];                           \
+        const uint32_t* soff_ = A.slice_off + size_t(fw) * kNumCodes;             \
+        A0 = soff_[code_]; B0 = soff_[code_ + 1];                                 \
+      }                                                                           \
+      if (++fq == Bn) { fq = 0; ++fw; }                                           \
+    }                                                                             \
+  } while (0)
+    uint4 u0, u1, u2;
+    bool head_any = false, head_more = false;
+    uint32_t hc0, hb0, hc1, hb1, hc2, hb2;
+#define BLURRILY_LOAD_HEAD(A0, B0)                                                                    \
+  do {                                                                                                \
+    head_any = head_units<kNW>(A0, B0, 0u, 0u, false, wid, lane, head_more, hc0, hb0, hc1, hb1, hc2,  \
+                               hb2);                                                                  \
+    u0 = load_group(A.ent, hc0, hb0);                                                                 \
+    u1 = load_group(A.ent, hc1, hb1);                                                                 \
+    u2 = load_group(A.ent, hc2, hb2);                                                                 \
+  } while (0)
+
+    BLURRILY_FETCH_STEP(ca, cb);
+    BLURRILY_FETCH_STEP(na, nb);
+    BLURRILY_LOAD_HEAD(ca, cb);
+
+    for (uint32_t w = 0; w < nwin; ++w) {
+      const uint32_t wbase = w * kWindowRanks;
+      const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+      for (uint32_t qi = 0; qi < Bn; ++qi) {
+        const bool any = head_any, more = head_more;
+        unsigned long long* pool = pools + size_t(qi) * MP;
+        if (any) {
+          bump8<CT>(cnt32, u0);
+          bump8<CT>(cnt32, u1);
+          bump8<CT>(cnt32, u2);
+          if (more) count_rest<CT, kNW>(A.ent, cnt32, ca, cb, 0u, 0u, false, wid, lane, 3u);
+          __syncthreads();                                      // counts visible
+        }
+        BLURRILY_LOAD_HEAD(na, nb);                             // next step's head, in flight during the scan
+        if (any) {
+          Needle nd; nd.T = meta[qi].T; nd.has_floor = false;
+          for (;;) {
+            scan_core<CT, NT>(cnt128, nd, meta[qi].thr, nullptr, pool, MP, &meta[qi].count, &ctl->overflow,
+                              wbase, wlen);
+            __syncthreads();                                    // counters are zero again
+            if (!ctl->overflow) {
+              // a filling pool is compacted by one wave while the others move on: the needle's
+              // state is next touched Bn steps (at least one barrier) from now
+              if (meta[qi].count > MP / 2 && wid == (qi & (kNW - 1))) wave_compact(pool, &meta[qi], MP, A.keep, lane);
+              break;
+            }
+            // The pool overflowed mid-window: keep the tightened threshold, forget this
+            // window's survivors and sweep the window again (see find_kernel).
+            if (wid == 0) {
+              wave_compact(pool, &meta[qi], MP, A.keep, lane);
+              if (lane == 0) {
+                uint32_t j = 0;
+                const uint32_t n = meta[qi].count;
+                for (uint32_t i = 0; i < n; ++i)
+                  if (uint32_t(pool[i]) < wbase) pool[j++] = pool[i];
+                meta[qi].count = j;
+                ctl->overflow = 0;
+              }
+            }
+            __syncthreads();
+            count_rest<CT, kNW>(A.ent, cnt32, ca, cb, 0u, 0u, false, wid, lane, 0u);
+            __syncthreads();
+          }
+        }
+        ca = na; cb = nb;
+        BLURRILY_FETCH_STEP(na, nb);
+      }
+    }
+#undef BLURRILY_LOAD_HEAD
+#undef BLURRILY_FETCH_STEP
+    __syncthreads();                                            // every async compaction has finished
+
+    // ---- emit: each wave finishes the needles it owns --------------------------------------
+    for (uint32_t qi = wid; qi < Bn; qi += kNW) {
+      unsigned long long* pool = pools + size_t(qi) * MP;
+      wave_compact(pool, &meta[qi], MP, A.keep, lane);
+      const uint32_t nres = meta[qi].count, q = meta[qi].q, T = meta[qi].T;
+      trigram_match_t* out = A.results + size_t(q) * A.limit;
+      for (uint32_t i = lane; i < nres; i += 64) {
+        const unsigned long long key = pool[i];
+        const uint32_t rk = uint32_t(key);
+        trigram_match_t r;
+        r.reference = A.ref_of_rank[rk];
+        r.matches = T - uint32_t(key >> 32);
+        r.weight = A.weight_of_rank[rk];
+        out[i] = r;
+      }
+      if (lane == 0) A.counts[q] = nres;
+    }
+    __syncthreads();
+  }
+}
+
+size_t find_block_lds_bytes(uint32_t block_size, uint32_t mini_cap) {
+  return size_t(kWindowSize) + size_t(block_size) * (size_t(mini_cap) * 8 + 64 * 2 + sizeof(BlockMeta)) +
+         sizeof(BlockControl) + 16;
 }
 
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
@@ -608,7 +889,7 @@ int launch_tokenise(const TokeniseArgs& t, hipStream_t stream) {
   const uint32_t block = 128;
   const uint32_t grid = (t.n + block - 1) / block;
   hipLaunchKernelGGL(tokenise_kernel, dim3(grid), dim3(block), 0, stream, t.packed, t.offsets, t.n,
-                     t.code_total, t.qcodes, t.q_ntri, t.q_nb, t.big_list, t.big_count);
+                     t.code_total, t.qcodes, t.q_ntri, t.q_nb, t.big_list, t.big_count, t.mid_list, t.mid_count);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -619,18 +900,66 @@ uint32_t find_pool_cap(uint32_t keep) {
   return cap;
 }
 
-template <typename CT, int NT>
-static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
+template <typename CT, int NT, bool RANGED>
+static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   const size_t lds = find_lds_bytes(sizeof(CT), a.pool_cap);
   static bool attr_done = false;
   if (!attr_done) {
-    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT>),
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((find_kernel<CT, NT>), dim3(grid), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
+}
+
+template <typename CT, int NT>
+static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
+  if (a.ranges > 1) return launch_find_tr<CT, NT, true>(a, grid, stream);
+  return launch_find_tr<CT, NT, false>(a, grid, stream);
+}
+
+int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) {
+  if (n_items == 0) return 0;
+  constexpr int NT = 1024;                                    // keep <= 1024 keys per range
+  const size_t lds = size_t(a.pool_cap) * 8 + sizeof(Control) + 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_parts_kernel<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((merge_parts_kernel<NT>), dim3(n_items), dim3(NT), lds, stream, a);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_find_block(const FindArgs& a, uint32_t grid, hipStream_t stream) {
+  if (grid == 0) return 0;
+  constexpr int NT = 1024;
+  const size_t lds = find_block_lds_bytes(a.block_size, a.pool_cap);
+  static bool attr_done = false;
+  if (!attr_done) {
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_block_kernel<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((find_block_kernel<NT>), dim3(grid), dim3(NT), lds, stream, a);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Largest block (needles per workgroup) whose state fits beside the counters with two
+// workgroups per CU (80 KiB each); 0 if the limit is too large for block mode.
+uint32_t find_block_size(uint32_t keep, uint32_t* mini_cap) {
+  uint32_t cap = 32;
+  while (cap < 3 * keep) cap <<= 1;
+  *mini_cap = cap;
+  const size_t budget = 80 * 1024 - 256;
+  uint32_t b = 64;
+  while (b > 0 && find_block_lds_bytes(b, cap) > budget) --b;
+  return b >= 8 ? b : 0;
 }
 
 int find_threads() {
