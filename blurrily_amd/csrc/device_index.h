@@ -11,8 +11,9 @@
 //     the side tables read when result rows are written.
 //   * the rank space is cut into windows of kWindowRanks = 65 535 ranks; the
 //     postings are stored window-major: for window w, for trigram code t, the
-//     16-bit in-window ranks (in no particular order: counting does not care)
-//     of the references whose string contains t.
+//     16-bit in-window ranks of the references whose string contains t, sorted,
+//     each 512-entry unit (one wave-load) stored transposed so that one LDS
+//     atomic instruction of the kernel covers consecutive sorted ranks.
 //     slice_off[w * kNumCodes + t] is the start of that slice in `ent`
 //     (a CSR over (window, code)); one extra element closes the last slice.
 //     Every slice starts on a 16-byte boundary and is padded to a multiple of

@@ -4,9 +4,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace blurrily {
@@ -111,61 +113,120 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   std::vector<Entry>().swap(refs);
 
   // ---- 2. rank every posting, count per (window, code) ----------------------
+  // Buckets are independent (a code's counts, cursors and slices are touched by one worker
+  // only), so steps 2 and 3 run on a pool of host threads that pull codes from a shared counter.
   const uint64_t n_slices = uint64_t(n_win) * kNumCodes;
   if (n_slices + 1 > 0x7FFFFFFFull) { errno = ENOMEM; return -1; }
   std::vector<uint32_t> slice_off(n_slices + 1, 0);
   std::vector<uint32_t> rank(nnz);
   std::vector<uint32_t> code_total(kNumCodes);
-  std::vector<Entry> scratch;
-  {
-    uint64_t idx = 0;
-    for (uint32_t t = 0; t < kNumCodes; ++t) {
-      const Bucket& bk = host.bucket(t);
-      code_total[t] = bk.used;
-      if (!bk.used) continue;
-      const Entry* e = sorted_view(bk, scratch);
-      uint64_t pos = 0;                       // references ascend inside a bucket: gallop from the last hit
-      for (uint32_t j = 0; j < bk.used; ++j) {
-        const uint32_t ref = e[j].ref;
-        uint64_t lo = pos, step = 1;
-        while (lo + step < n_refs && sorted_ref[lo + step] < ref) { lo += step; step <<= 1; }
-        uint64_t hi = std::min<uint64_t>(lo + step, n_refs ? n_refs - 1 : 0);
-        while (lo < hi) {                     // first position in [lo, hi] with sorted_ref >= ref
-          const uint64_t mid = (lo + hi) >> 1;
-          if (sorted_ref[mid] < ref) lo = mid + 1; else hi = mid;
-        }
-        if (lo >= n_refs || sorted_ref[lo] != ref || (j > 0 && lo < pos)) { errno = EPROTO; return -1; }
-        const uint32_t rk = rank_of_pos[lo];
-        if (weight_of_rank[rk] != e[j].weight) { errno = EPROTO; return -1; }   // one weight per reference
-        rank[idx++] = rk;
-        slice_off[uint64_t(rk / kWindowRanks) * kNumCodes + t + 1] += 1;
-        pos = lo + 1;                         // strictly ascending: a duplicate ref fails the lookup above
-      }
-    }
+  std::vector<uint64_t> bucket_base(kNumCodes + 1, 0);
+  for (uint32_t t = 0; t < kNumCodes; ++t) {
+    code_total[t] = host.bucket(t).used;
+    bucket_base[t + 1] = bucket_base[t] + code_total[t];
   }
+  const unsigned n_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+  std::atomic<int> failed{0};
+  auto parallel_codes = [&](auto&& body) {
+    std::atomic<uint32_t> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const uint32_t t0 = next.fetch_add(64);
+        if (t0 >= kNumCodes || failed.load()) return;
+        for (uint32_t t = t0; t < std::min(t0 + 64, kNumCodes); ++t) body(t);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  };
+
+  parallel_codes([&](uint32_t t) {
+    const Bucket& bk = host.bucket(t);
+    if (!bk.used) return;
+    std::vector<Entry> scratch;
+    const Entry* e = sorted_view(bk, scratch);
+    uint32_t* out_rank = rank.data() + bucket_base[t];
+    uint64_t pos = 0;                         // references ascend inside a bucket: gallop from the last hit
+    for (uint32_t j = 0; j < bk.used; ++j) {
+      const uint32_t ref = e[j].ref;
+      uint64_t lo = pos, step = 1;
+      while (lo + step < n_refs && sorted_ref[lo + step] < ref) { lo += step; step <<= 1; }
+      uint64_t hi = std::min<uint64_t>(lo + step, n_refs ? n_refs - 1 : 0);
+      while (lo < hi) {                       // first position in [lo, hi] with sorted_ref >= ref
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sorted_ref[mid] < ref) lo = mid + 1; else hi = mid;
+      }
+      // a reference missing from the table, listed twice in the bucket, or with a second weight
+      if (lo >= n_refs || sorted_ref[lo] != ref || (j > 0 && lo < pos) ||
+          weight_of_rank[rank_of_pos[lo]] != e[j].weight) {
+        failed.store(1);
+        return;
+      }
+      const uint32_t rk = rank_of_pos[lo];
+      out_rank[j] = rk;
+      slice_off[uint64_t(rk / kWindowRanks) * kNumCodes + t + 1] += 1;
+      pos = lo + 1;
+    }
+  });
+  if (failed.load()) { errno = EPROTO; return -1; }
+
   // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum
   uint64_t n_slots = 0;
   for (uint64_t i = 0; i < n_slices; ++i) {
     const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
-    slice_off[i + 1] = 0;                     // becomes the running end below
     n_slots += len;
     if (n_slots > 0xFFFF0000ull) { errno = EPROTO; return -1; }
     slice_off[i + 1] = uint32_t(n_slots);
   }
 
-  // ---- 3. scatter into window-major slices ----------------------------------
+  // ---- 3. scatter into window-major slices; deal every unit bank-aware ---------
+  // The kernel bumps one packed byte counter per posting with an LDS atomic whose bank is
+  // (rank >> 2) & 31; a wave instruction serialises lanes of one 32-lane half that hit the same
+  // bank (46 % of the LDS-active cycles with postings in arbitrary order,
+  // profiles/r01_pmc_lds.txt) or the same word.  Inside each unit (the 64 x 16 bytes one wave
+  // loads; lane l's j-th element is bumped by instruction j) the postings are therefore dealt
+  // in (bank, rank) order round-robin over the 16 instruction-halves, so one half sees each
+  // bank -- and each counter word -- about once.
   std::vector<uint16_t> ent(n_slots + kEntPad, kPadRank);
-  {
-    std::vector<uint32_t> cursor(slice_off.begin(), slice_off.end() - 1);
-    uint64_t idx = 0;
-    for (uint32_t t = 0; t < kNumCodes; ++t) {
-      const uint32_t used = host.bucket(t).used;
-      for (uint32_t j = 0; j < used; ++j) {
-        const uint32_t r = rank[idx++];
-        ent[cursor[uint64_t(r / kWindowRanks) * kNumCodes + t]++] = uint16_t(r % kWindowRanks);
+  parallel_codes([&](uint32_t t) {
+    const uint32_t used = code_total[t];
+    if (!used) return;
+    const uint32_t* rk = rank.data() + bucket_base[t];
+    std::vector<uint32_t> fill(n_win, 0);
+    for (uint32_t j = 0; j < used; ++j) {
+      const uint32_t w = rk[j] / kWindowRanks;
+      ent[slice_off[uint64_t(w) * kNumCodes + t] + fill[w]++] = uint16_t(rk[j] % kWindowRanks);
+    }
+    std::vector<uint16_t> tmp;
+    for (uint32_t w = 0; w < n_win; ++w) {
+      const uint32_t m = fill[w];
+      if (m < 16) continue;                                   // a lane or two: nothing to arrange
+      uint16_t* sl = ent.data() + slice_off[uint64_t(w) * kNumCodes + t];
+      const uint32_t padded = (m + 7u) & ~7u;
+      for (uint32_t u0 = 0; u0 < padded; u0 += 512) {         // one wave-load at a time
+        const uint32_t len = std::min(512u, padded - u0), G = len / 8;
+        const uint32_t real = std::min(len, m - u0);          // padding sentinels sit at the end
+        tmp.assign(sl + u0, sl + u0 + real);
+        std::sort(tmp.begin(), tmp.end(), [](uint16_t x, uint16_t y) {
+          const uint32_t bx = (x >> 2) & 31u, by = (y >> 2) & 31u;
+          return bx != by ? bx < by : x < y;
+        });
+        // 16 instruction-halves: h = 2*j + (lane >= 32); capacity = live lanes in that half
+        uint32_t cap[16], cnt[16];
+        for (uint32_t h = 0; h < 16; ++h) { cap[h] = (h & 1) ? (G > 32 ? G - 32 : 0) : std::min(G, 32u); cnt[h] = 0; }
+        std::fill(sl + u0, sl + u0 + len, kPadRank);
+        uint32_t h = 0;
+        for (uint32_t i = 0; i < real; ++i) {
+          while (cnt[h] == cap[h]) h = (h + 1) & 15;
+          const uint32_t lane = (h & 1) * 32 + cnt[h]++;
+          sl[u0 + lane * 8 + (h >> 1)] = tmp[i];
+          h = (h + 1) & 15;
+        }
       }
     }
-  }
+  });
   std::vector<uint32_t>().swap(rank);
 
   // ---- 4. upload -------------------------------------------------------------
