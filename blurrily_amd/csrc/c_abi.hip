@@ -193,12 +193,19 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
       // needles with > 127 distinct trigrams are skipped by the byte-counter kernel: their
       // tasks must not leave stale counts behind for the merge
       BLURRILY_HIP_TRY(hipMemsetAsync(a.part_count, 0, tasks * 4, stream));
+      a.short_only = 1;
       if (launch_find(a, false, uint32_t(std::min<size_t>(tasks, wgs)), stream) < 0) return -1;
       uint32_t merge_cap = 1024;
       while (merge_cap < ranges * limit) merge_cap <<= 1;
       a.pool_cap = merge_cap;
       if (launch_merge_parts(a, uint32_t(n), stream) < 0) return -1;
-      a.ranges = 0; a.part_keys = nullptr; a.part_count = nullptr;
+      a.ranges = 0; a.part_keys = nullptr; a.part_count = nullptr; a.short_only = 0;
+      if (maybe_mid) {                               // 65..127 distinct trigrams: whole needle per workgroup
+        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+        a.pool_cap = find_pool_cap(a.keep);
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        if (launch_find(a, false, uint32_t(std::min<size_t>(n, size_t(m->n_cus))), stream) < 0) return -1;
+      }
     }
     // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
     for (uint32_t base = 0; !block && ranges <= 1 && base < limit; base += 1024) {
@@ -207,7 +214,14 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
       a.pool_cap = find_pool_cap(a.keep);
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
       const uint32_t grid = uint32_t(std::min<size_t>(n, wgs));
+      a.short_only = 1;                              // needles with <= 64 distinct trigrams
       if (launch_find(a, false, grid, stream) < 0) return -1;
+      a.short_only = 0;
+      if (maybe_mid) {                               // 65..127: the tokeniser's mid list
+        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        if (launch_find(a, false, uint32_t(std::min<size_t>(n, size_t(m->n_cus))), stream) < 0) return -1;
+      }
     }
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
     if (maybe_long) {

@@ -52,6 +52,7 @@ struct FindArgs {
   uint32_t        n_needles;   // block mode: needles in the batch (n_work counts blocks)
   unsigned long long* floor;   // [n] last key delivered by the previous pass (multi-pass only)
   // latency mode (small batches): every needle's windows are cut into `ranges` tasks
+  uint32_t        short_only;  // byte-counter launches: own only needles with <= 64 distinct trigrams
   uint32_t        ranges;      // 0/1: off
   unsigned long long* part_keys;   // [n_items * ranges * keep] best keys of every task
   uint32_t*       part_count;  // [n_items * ranges]

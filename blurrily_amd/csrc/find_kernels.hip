@@ -47,6 +47,10 @@ namespace {
 
 constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 
+#ifndef BLURRILY_HEAD_UNITS
+#define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
+#endif
+
 // Optional phase profile (make profile): wave 0's shader-clock time per phase of the sweep,
 // accumulated per workgroup into FindArgs::phase_clocks[blockIdx.x * 8 + phase].
 #ifdef BLURRILY_PHASE_PROFILE
@@ -408,56 +412,64 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
     }                                                                                            \
   } while (0)
 
-// Head of a window: the first three units of this wave (c == b == 0: no such unit).
+// Head of a window: the first KP (<= 4) units of this wave (c == b == 0: no such unit).
 // `more` = the wave owns further units; returns true if the window holds any posting.
-template <int kNW>
+template <int kNW, int KP>
 __device__ __forceinline__ bool head_units(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, bool two_slots,
                                            uint32_t wid, uint32_t lane, bool& more, uint32_t& c0, uint32_t& e0,
-                                           uint32_t& c1, uint32_t& e1, uint32_t& c2, uint32_t& e2) {
-  uint32_t k = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-  BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, {
-    x0 = k == 0 ? c : x0; y0 = k == 0 ? sb : y0;
-    x1 = k == 1 ? c : x1; y1 = k == 1 ? sb : y1;
-    x2 = k == 2 ? c : x2; y2 = k == 2 ? sb : y2;
-  });
-  if (two_slots) {
-    BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, {
-      x0 = k == 0 ? c : x0; y0 = k == 0 ? sb : y0;
-      x1 = k == 1 ? c : x1; y1 = k == 1 ? sb : y1;
-      x2 = k == 2 ? c : x2; y2 = k == 2 ? sb : y2;
-    });
+                                           uint32_t& c1, uint32_t& e1, uint32_t& c2, uint32_t& e2, uint32_t& c3,
+                                           uint32_t& e3) {
+  uint32_t k = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0, x3 = 0, y3 = 0;
+#define BLURRILY_KEEP_HEAD                                   \
+  {                                                          \
+    x0 = k == 0 ? c : x0; y0 = k == 0 ? sb : y0;             \
+    x1 = k == 1 ? c : x1; y1 = k == 1 ? sb : y1;             \
+    x2 = k == 2 ? c : x2; y2 = k == 2 ? sb : y2;             \
+    if (KP > 3) { x3 = k == 3 ? c : x3; y3 = k == 3 ? sb : y3; } \
   }
-  c0 = x0; e0 = y0; c1 = x1; e1 = y1; c2 = x2; e2 = y2;
-  more = k > 3;
+  BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, BLURRILY_KEEP_HEAD);
+  if (two_slots) BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, BLURRILY_KEEP_HEAD);
+#undef BLURRILY_KEEP_HEAD
+  c0 = x0; e0 = y0; c1 = x1; e1 = y1; c2 = x2; e2 = y2; c3 = x3; e3 = y3;
+  more = k > uint32_t(KP);
   return (__ballot(b0 > a0) | __ballot(b1 > a1)) != 0;
 }
 
-// Units of this wave beyond the first `skip`: loaded and counted in place.
+// Units of this wave beyond the first `skip`: loaded and counted in place, one unit's LDS
+// atomics running while the next unit's load is in flight.
 template <typename CT, int kNW>
 __device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32, uint32_t a0, uint32_t b0,
                                            uint32_t a1, uint32_t b1, bool two_slots, uint32_t wid,
                                            uint32_t lane, uint32_t skip) {
   uint32_t k = 0;
-  BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, { if (k >= skip) bump8<CT>(cnt32, load_group(ent, c, sb)); });
+  uint4 pend = make_uint4(~0u, ~0u, ~0u, ~0u);
+  BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, {
+    if (k >= skip) { const uint4 v = load_group(ent, c, sb); bump8<CT>(cnt32, pend); pend = v; }
+  });
   if (two_slots)
-    BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, { if (k >= skip) bump8<CT>(cnt32, load_group(ent, c, sb)); });
+    BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, {
+      if (k >= skip) { const uint4 v = load_group(ent, c, sb); bump8<CT>(cnt32, pend); pend = v; }
+    });
+  bump8<CT>(cnt32, pend);
 }
 
 // Software-pipelined sweep: every wave keeps the needle's slice tables of windows w and w+1 in
 // registers and, while window w is scanned, already has its first three units of window w+1
 // in flight.  A window costs two barriers and, in steady state, no exposed global-memory
 // round trip.
-template <typename CT, int NT>
+// SLOTS2: the needle may have more than 64 distinct trigrams (second table slot per lane);
+// KP: units of the next window kept in flight (3, or 4 when the second slot's registers are free).
+template <typename CT, int NT, bool SLOTS2, int KP>
 __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
                                 unsigned long long* pool, Control* ctl, const uint32_t w0, const uint32_t w1) {
   constexpr uint32_t kNW = NT / 64;
-  constexpr uint32_t kPre = 3;                                  // units loaded one window ahead
+  constexpr uint32_t kPre = KP;                                 // units loaded one window ahead
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t tc = nd.T;                                     // <= 128
   const uint32_t nwin = w1;                                     // windows [w0, w1) of the rank space
-  const bool two_slots = tc > 64;
+  const bool two_slots = SLOTS2 && tc > 64;
 
-  const bool own0 = lane < tc, own1 = lane + 64 < tc;
+  const bool own0 = lane < tc, own1 = SLOTS2 && lane + 64 < tc;
   const uint32_t code0 = own0 ? codes[lane] : 0u;
   const uint32_t code1 = own1 ? codes[lane + 64] : 0u;
   // slice tables of window w (ca*/cb*) and w+1 (na*/nb*), plain registers
@@ -468,21 +480,22 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     if ((w_) < nwin) {                                                           \
       const uint32_t* soff_ = A.slice_off + size_t(w_) * kNumCodes;              \
       if (own0) { A0 = soff_[code0]; B0 = soff_[code0 + 1]; }                    \
-      if (own1) { A1 = soff_[code1]; B1 = soff_[code1 + 1]; }                    \
+      if (SLOTS2 && own1) { A1 = soff_[code1]; B1 = soff_[code1 + 1]; }          \
     }                                                                            \
   } while (0)
 
   // head of a window: its first kPre units of this wave, loaded ahead of time
-  uint4 u0, u1, u2;
+  uint4 u0, u1, u2, u3 = make_uint4(~0u, ~0u, ~0u, ~0u);
   bool head_any = false, head_more = false;                     // of the window the head belongs to
-  uint32_t hc0, hb0, hc1, hb1, hc2, hb2;
+  uint32_t hc0, hb0, hc1, hb1, hc2, hb2, hc3, hb3;
 #define BLURRILY_LOAD_HEAD(A0, B0, A1, B1)                                                          \
   do {                                                                                              \
-    head_any = head_units<kNW>(A0, B0, A1, B1, two_slots, wid, lane, head_more, hc0, hb0, hc1, hb1, \
-                               hc2, hb2);                                                           \
+    head_any = head_units<kNW, KP>(A0, B0, A1, B1, two_slots, wid, lane, head_more, hc0, hb0, hc1,  \
+                                   hb1, hc2, hb2, hc3, hb3);                                        \
     u0 = load_group(A.ent, hc0, hb0);                                                               \
     u1 = load_group(A.ent, hc1, hb1);                                                               \
     u2 = load_group(A.ent, hc2, hb2);                                                               \
+    if (KP > 3) u3 = load_group(A.ent, hc3, hb3);                                                   \
   } while (0)
 
   BLURRILY_FETCH_TABLE(w0, ca0, cb0, ca1, cb1);
@@ -500,6 +513,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
       bump8<CT>(cnt32, u0);
       bump8<CT>(cnt32, u1);
       bump8<CT>(cnt32, u2);
+      if (KP > 3) bump8<CT>(cnt32, u3);
       PHASE_MARK(1);                                            // head counted
       if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre);
       PHASE_MARK(2);                                            // rest counted
@@ -530,8 +544,10 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 }
 
 // RANGED = latency mode (a needle's windows cut into ranges); a separate instantiation so the
-// throughput kernel does not carry the extra live registers.
-template <typename CT, int NT, bool RANGED>
+// throughput kernel does not carry the extra live registers.  SHORT = the launch owns only
+// needles with <= 64 distinct trigrams (one table slot per lane, which frees the registers for a
+// fourth unit in flight); 65..127 follow in a launch over the tokeniser's mid list.
+template <typename CT, int NT, bool RANGED, bool SHORT>
 __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // carve: counters | candidate pool | slice table (long needles) | control
@@ -563,7 +579,10 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     const uint32_t w1 = RANGED ? uint32_t(uint64_t(A.n_windows) * (range + 1) / R) : A.n_windows;
     Needle nd;
     nd.T = A.q_ntri[q];
-    if (!A.work_list && nd.T > 127) continue;          // long needles go to the uint16_t launch
+    if (!A.work_list && nd.T > (SHORT ? 64u : 127u)) { // longer needles: the mid / wide-counter launches
+      if (RANGED && tid == 0) A.part_count[slot] = 0;
+      continue;
+    }
     const uint32_t have = A.pass_base ? A.counts[q] : 0u;
     if (A.q_nb[q] == 0 || A.keep == 0 || have < A.pass_base) {
       if (tid == 0 && A.pass_base == 0) {
@@ -581,10 +600,12 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     }
     __syncthreads();
 
-    if constexpr (sizeof(CT) == 1) {                 // byte counters: T <= 127 by construction
-      sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+    if constexpr (SHORT) {
+      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+    } else if constexpr (sizeof(CT) == 1) {          // byte counters: T <= 127 by construction
+      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1);
     } else {
-      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1);
       else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, w0, w1);
     }
 
@@ -778,11 +799,11 @@ __global__ __launch_bounds__(NT, 8) void find_block_kernel(const FindArgs A) {
   } while (0)
     uint4 u0, u1, u2;
     bool head_any = false, head_more = false;
-    uint32_t hc0, hb0, hc1, hb1, hc2, hb2;
+    uint32_t hc0, hb0, hc1, hb1, hc2, hb2, hc3, hb3;
 #define BLURRILY_LOAD_HEAD(A0, B0)                                                                    \
   do {                                                                                                \
-    head_any = head_units<kNW>(A0, B0, 0u, 0u, false, wid, lane, head_more, hc0, hb0, hc1, hb1, hc2,  \
-                               hb2);                                                                  \
+    head_any = head_units<kNW, 3>(A0, B0, 0u, 0u, false, wid, lane, head_more, hc0, hb0, hc1, hb1,    \
+                                  hc2, hb2, hc3, hb3);                                                \
     u0 = load_group(A.ent, hc0, hb0);                                                                 \
     u1 = load_group(A.ent, hc1, hb1);                                                                 \
     u2 = load_group(A.ent, hc2, hb2);                                                                 \
@@ -904,24 +925,30 @@ uint32_t find_pool_cap(uint32_t keep) {
   return cap;
 }
 
-template <typename CT, int NT, bool RANGED>
+template <typename CT, int NT, bool RANGED, bool SHORT>
 static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   const size_t lds = find_lds_bytes(sizeof(CT), a.pool_cap);
   static bool attr_done = false;
   if (!attr_done) {
-    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED>),
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED>), dim3(grid), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }
 
 template <typename CT, int NT>
 static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
-  if (a.ranges > 1) return launch_find_tr<CT, NT, true>(a, grid, stream);
-  return launch_find_tr<CT, NT, false>(a, grid, stream);
+  if constexpr (sizeof(CT) == 1) {
+    if (a.short_only) {
+      if (a.ranges > 1) return launch_find_tr<CT, NT, true, true>(a, grid, stream);
+      return launch_find_tr<CT, NT, false, true>(a, grid, stream);
+    }
+  }
+  if (a.ranges > 1) return launch_find_tr<CT, NT, true, false>(a, grid, stream);
+  return launch_find_tr<CT, NT, false, false>(a, grid, stream);
 }
 
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) {
