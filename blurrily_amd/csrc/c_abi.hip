@@ -158,7 +158,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
     uint32_t block = use_block_mode() ? find_block_size(limit, &mini_cap) : 0;
     if (block) {
       // at least ~4 blocks per resident workgroup so the tail stays short on small batches
-      const size_t wgs = size_t(m->n_cus) * 2;
+      const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
       while (block > 1 && (n + block - 1) / block < wgs * 4) block = (block + 1) / 2;
       a.work_list = nullptr; a.n_work_dev = nullptr;
       a.block_size = block; a.n_needles = uint32_t(n); a.n_work = uint32_t((n + block - 1) / block);
@@ -174,7 +174,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
     }
     // Latency mode: a batch too small to fill the GPU cuts every needle's windows into ranges
     // swept by different workgroups, then merges the per-range candidates (single pass only).
-    const size_t wgs = size_t(m->n_cus) * 2;
+    const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
     uint32_t ranges = 1;
     if (!block && limit <= 1024 && n < wgs / 2 && ix.n_windows > 1) {
       ranges = uint32_t(std::min<size_t>(ix.n_windows, (2 * wgs) / n));

@@ -32,10 +32,13 @@
 
 namespace blurrily {
 
-constexpr uint32_t kWindowBits  = 16;
+#ifndef BLURRILY_WINDOW_BITS
+#define BLURRILY_WINDOW_BITS 16          // experiments: 15 halves the counters (4 workgroups of 512 per CU)
+#endif
+constexpr uint32_t kWindowBits  = BLURRILY_WINDOW_BITS;
 constexpr uint32_t kWindowSize  = 1u << kWindowBits;    // counter slots per window (LDS)
 constexpr uint32_t kWindowRanks = kWindowSize - 1;      // ranks per window; slot 0xFFFF = padding sentinel
-constexpr uint16_t kPadRank     = 0xFFFF;
+constexpr uint16_t kPadRank     = uint16_t(kWindowSize - 1);
 constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byte over-reads)
 
 struct DeviceIndex {

@@ -60,7 +60,8 @@ struct FindArgs {
 };
 
 uint32_t find_pool_cap(uint32_t keep);
-int find_threads();   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
+int find_threads();
+uint32_t find_wgs_per_cu();   // resident byte-counter workgroups per CU (LDS and wave limits)   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 uint32_t find_block_size(uint32_t keep, uint32_t* mini_cap);

@@ -37,6 +37,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +65,7 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #define PHASE_FLUSH(A)
 #endif
 constexpr uint64_t kKeyInf    = ~0ull;
+constexpr uint32_t kPadPair   = uint32_t(kPadRank) | (uint32_t(kPadRank) << 16);   // two padding sentinels
 
 // --------------------------------------------------------------- tokeniser ---
 
@@ -185,7 +187,7 @@ __device__ __forceinline__ void bump8(uint32_t* cnt32, const uint4 v) {
 }
 
 __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uint32_t b) {
-  uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+  uint4 v = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   if (c < b) v = *reinterpret_cast<const uint4*>(ent + c);
   return v;
 }
@@ -442,7 +444,7 @@ __device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32,
                                            uint32_t a1, uint32_t b1, bool two_slots, uint32_t wid,
                                            uint32_t lane, uint32_t skip) {
   uint32_t k = 0;
-  uint4 pend = make_uint4(~0u, ~0u, ~0u, ~0u);
+  uint4 pend = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, {
     if (k >= skip) { const uint4 v = load_group(ent, c, sb); bump8<CT>(cnt32, pend); pend = v; }
   });
@@ -485,7 +487,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
   } while (0)
 
   // head of a window: its first kPre units of this wave, loaded ahead of time
-  uint4 u0, u1, u2, u3 = make_uint4(~0u, ~0u, ~0u, ~0u);
+  uint4 u0, u1, u2, u3 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   bool head_any = false, head_more = false;                     // of the window the head belongs to
   uint32_t hc0, hb0, hc1, hb1, hc2, hb2, hc3, hb3;
 #define BLURRILY_LOAD_HEAD(A0, B0, A1, B1)                                                          \
@@ -1001,6 +1003,12 @@ int find_threads() {
     if (nt != 256 && nt != 512 && nt != 1024) nt = 1024;
   }
   return nt;
+}
+
+uint32_t find_wgs_per_cu() {
+  const uint32_t by_lds = uint32_t((160 * 1024) / find_lds_bytes(1, 1024));
+  const uint32_t by_waves = 32u / uint32_t(find_threads() / 64);
+  return std::max(1u, std::min(by_lds, by_waves));
 }
 
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
