@@ -102,7 +102,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   if (m->ws_codes.reserve(align_up(code_slots * sizeof(uint16_t), 256), stream) < 0) return -1;
   const size_t per_n = align_up(n * sizeof(uint32_t), 256);
   const bool multi_pass = limit > 256;             // long needles keep 256 rows per pass, short ones 1024
-  const size_t small_bytes = per_n * 4 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
+  const size_t small_bytes = per_n * 5 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
   if (m->ws_small.reserve(small_bytes, stream) < 0) return -1;
   unsigned char* sp = static_cast<unsigned char*>(m->ws_small.p);
   uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1]=mid_count [2..]=queues
@@ -110,6 +110,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   uint32_t* q_nb_ws  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* big_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* mid_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
+  uint32_t* q_start  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   unsigned long long* floor = nullptr;
   if (multi_pass) floor = reinterpret_cast<unsigned long long*>(sp);
   uint32_t* q_nb = d_nb ? d_nb : q_nb_ws;
@@ -117,7 +118,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
 
   if (m->timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev[0], stream));
   TokeniseArgs t{d_packed, d_offsets, uint32_t(n), ix.d_code_total, static_cast<uint16_t*>(m->ws_codes.p),
-                 q_ntri, q_nb, big_list, scalars, mid_list, scalars + 1};
+                 q_ntri, q_nb, big_list, scalars, mid_list, scalars + 1, ix.d_start_win, q_start};
   if (launch_tokenise(t, stream) < 0) return -1;
   if (m->timing) {
     BLURRILY_HIP_TRY(hipEventRecord(m->ev[1], stream));
@@ -128,7 +129,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   a.slice_off = ix.d_slice_off; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
   a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
   a.offsets = d_offsets; a.qcodes = static_cast<const uint16_t*>(m->ws_codes.p);
-  a.q_ntri = q_ntri; a.q_nb = q_nb; a.results = d_results; a.counts = d_counts; a.limit = limit;
+  a.q_ntri = q_ntri; a.q_nb = q_nb; a.q_start = q_start; a.win_max_tri = ix.d_win_max_tri; a.results = d_results; a.counts = d_counts; a.limit = limit;
   a.floor = floor;
 #ifdef BLURRILY_PHASE_PROFILE
   {

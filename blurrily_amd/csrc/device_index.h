@@ -22,6 +22,12 @@
 //     range check; counter slot 0xFFFF is a scratch slot the scan ignores.
 //   * code_total[t] = used[t] of the reference's bucket t (storage.c:501), for
 //     the matched-entries metric.
+//   * win_max_tri[w]: the largest number of postings (= distinct trigrams) any one
+//     reference of window w has -- no reference of w can match more trigrams than
+//     that, so a window whose bound is below the admission threshold is skipped.
+//     start_win[L]: the window holding the first rank with weight >= L; a sweep
+//     starts at the window of the needle's own length (weight defaults to strlen,
+//     storage.c:409), where its best matches live, so the threshold tightens early.
 // An entry costs 2 bytes in HBM instead of the reference's 8-byte
 // (reference, weight) pair; the algorithmic byte count of DESIGN.md keeps the
 // reference's 8 bytes.
@@ -54,6 +60,8 @@ struct DeviceIndex {
   uint32_t* d_slice_off      = nullptr;   // [n_windows * kNumCodes + 1]
   uint16_t* d_ent            = nullptr;   // [n_slots + kEntPad]
   uint32_t* d_code_total     = nullptr;   // [kNumCodes]
+  uint32_t* d_win_max_tri    = nullptr;   // [n_windows] most postings any one reference of the window has
+  uint32_t* d_start_win      = nullptr;   // [256] window holding the first rank whose weight is >= the index
 };
 
 // Build the device image of `host` on the current HIP device.  Returns 0, or

@@ -48,6 +48,8 @@ void device_index_free(DeviceIndex* ix) {
   if (ix->d_slice_off)      (void)hipFree(ix->d_slice_off);
   if (ix->d_ent)            (void)hipFree(ix->d_ent);
   if (ix->d_code_total)     (void)hipFree(ix->d_code_total);
+  if (ix->d_win_max_tri)    (void)hipFree(ix->d_win_max_tri);
+  if (ix->d_start_win)      (void)hipFree(ix->d_start_win);
   *ix = DeviceIndex();
 }
 
@@ -227,6 +229,21 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
       }
     }
   });
+  // per-window bound and per-weight start window
+  std::vector<uint32_t> win_max_tri(n_win, 0), start_win(256, n_win - 1);
+  {
+    std::vector<uint16_t> ntri(n_refs, 0);
+    for (uint64_t i = 0; i < nnz; ++i) ntri[rank[i]] += 1;     // <= 19 683 codes per reference
+    for (uint32_t r = 0; r < n_refs; ++r) {
+      uint32_t& mx = win_max_tri[r / kWindowRanks];
+      mx = std::max<uint32_t>(mx, ntri[r]);
+    }
+    uint32_t r = 0;
+    for (uint32_t L = 0; L < 256; ++L) {
+      while (r < n_refs && weight_of_rank[r] < L) ++r;
+      start_win[L] = r < n_refs ? r / kWindowRanks : n_win - 1;
+    }
+  }
   std::vector<uint32_t>().swap(rank);
 
   // ---- 4. upload -------------------------------------------------------------
@@ -242,7 +259,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     return 0;
   };
   if (up(&ix.d_ref_of_rank, ref_of_rank, 1) || up(&ix.d_weight_of_rank, weight_of_rank, 1) ||
-      up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1)) {
+      up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
+      up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1)) {
     const int e = errno;
     device_index_free(&ix);
     errno = e;

@@ -22,6 +22,8 @@ struct TokeniseArgs {
   uint32_t*       big_count;   // [1]
   uint32_t*       mid_list;    // [n] needles with 65..127 distinct trigrams
   uint32_t*       mid_count;   // [1]
+  const uint32_t* start_win;   // [256] index table: first window of a weight
+  uint32_t*       q_start;     // [n] window a needle's sweep starts at
 };
 
 struct FindArgs {
@@ -37,6 +39,8 @@ struct FindArgs {
   const uint16_t* qcodes;
   const uint32_t* q_ntri;
   const uint32_t* q_nb;
+  const uint32_t* q_start;     // [n] window the sweep starts at (the needle's own length class)
+  const uint32_t* win_max_tri; // [n_windows] match-count bound per window
   const uint32_t* work_list;   // nullptr: slots are needle ids, long needles skipped
   const uint32_t* n_work_dev;  // when set, the number of slots is read from the device
   uint32_t        n_work;

@@ -78,7 +78,8 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
                                 uint16_t* __restrict__ qcodes, uint32_t* __restrict__ q_ntri,
                                 uint32_t* __restrict__ q_nb, uint32_t* __restrict__ big_list,
                                 uint32_t* __restrict__ big_count, uint32_t* __restrict__ mid_list,
-                                uint32_t* __restrict__ mid_count) {
+                                uint32_t* __restrict__ mid_count, const uint32_t* __restrict__ start_win,
+                                uint32_t* __restrict__ q_start) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const uint64_t beg = offsets[q], end = offsets[q + 1];
@@ -130,6 +131,7 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
     if (d == 0 || out[d - 1] != v) { out[d++] = v; nb += code_total[v]; }
   }
   q_ntri[q] = d;
+  q_start[q] = start_win[len < 255 ? len : 255];   // where references as long as the needle live
   q_nb[q] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
   if (d > 127) big_list[atomicAdd(big_count, 1u)] = q;            // 16-bit counters
   else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, but not block mode
@@ -228,6 +230,15 @@ struct Needle {
   bool has_floor;                   // later pass of a limit larger than the pool (floor key in Control)
 };
 
+// A counter of the window starting at rank `wbase` must reach this many matches to beat the
+// current keep-th candidate `thr`: its match count, or one more when the whole window lies
+// behind that candidate's rank (a tie loses to the lower rank).  Valid for any sweep order.
+__device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint32_t T, uint32_t wbase) {
+  if (thr == kKeyInf) return 1u;
+  const uint32_t matches_k = T - uint32_t(thr >> 32);
+  return max(1u, uint32_t(thr) >= wbase ? matches_k : matches_k + 1);
+}
+
 // ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
@@ -237,13 +248,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
   using P = Packing<CT>;
   constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
   const uint32_t tid = threadIdx.x;
-  // A counter must reach `need` to beat the current keep-th candidate: its match count, or one
-  // more once the sweep has passed that candidate's rank (ties lose to the lower rank).
-  uint32_t need = 1;
-  if (thr != kKeyInf) {
-    const uint32_t matches_k = nd.T - uint32_t(thr >> 32);
-    need = max(1u, uint32_t(thr) >= wbase ? matches_k : matches_k + 1);
-  }
+  const uint32_t need = matches_needed(thr, nd.T, wbase);
   const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
   if (need <= nd.T) {
     const uint32_t bias = (P::kTop - need) * P::kOnes;
@@ -308,7 +313,7 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
 // overflowed during the scan of this window, i.e. the window has to be swept again.
 template <int NT>
 __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned long long* pool, Control* ctl,
-                                                  uint32_t wbase) {
+                                                  uint32_t wbase, uint32_t wlen) {
   const uint32_t ov = ctl->overflow;
   const uint32_t pn = ctl->pool_n;
   if (!(ov || pn > A.pool_cap / 2)) return false;
@@ -321,7 +326,7 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
     uint32_t j = 0;
     const uint32_t n = ctl->pool_n;
     for (uint32_t i = 0; i < n; ++i)
-      if (uint32_t(pool[i]) < wbase) pool[j++] = pool[i];
+      if (uint32_t(pool[i]) - wbase >= wlen) pool[j++] = pool[i];     // not of this window (any sweep order)
     ctl->pool_n = j;
   }
   __syncthreads();
@@ -383,7 +388,7 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
       if (!touched) break;                                      // nothing of this needle in the window
       scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
       __syncthreads();
-      redo = select_after_scan<NT>(A, pool, ctl, wbase);
+      redo = select_after_scan<NT>(A, pool, ctl, wbase, wlen);
     } while (redo);
   }
 }
@@ -463,7 +468,11 @@ __device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32,
 // KP: units of the next window kept in flight (3, or 4 when the second slot's registers are free).
 template <typename CT, int NT, bool SLOTS2, int KP>
 __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
-                                unsigned long long* pool, Control* ctl, const uint32_t w0, const uint32_t w1) {
+                                unsigned long long* pool, Control* ctl, const uint32_t w0, const uint32_t w1,
+                                const uint32_t ws) {
+  // Windows [w0, w1) are visited starting at `ws` and wrapping around: the needle's own length
+  // class first (its best matches, so the threshold tightens early), the rest after.  A window
+  // whose references cannot reach the threshold (win_max_tri) is skipped without being loaded.
   constexpr uint32_t kNW = NT / 64;
   constexpr uint32_t kPre = KP;                                 // units loaded one window ahead
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -500,12 +509,20 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     if (KP > 3) u3 = load_group(A.ent, hc3, hb3);                                                   \
   } while (0)
 
-  BLURRILY_FETCH_TABLE(w0, ca0, cb0, ca1, cb1);
-  BLURRILY_FETCH_TABLE(w0 + 1, na0, nb0, na1, nb1);
+  const uint32_t n_visit = w1 - w0;
+  // i-th window of the sweep; past the end: w1 (an empty table)
+#define BLURRILY_WIN_AT(i_) ((i_) < n_visit ? (ws + (i_) < w1 ? ws + (i_) : ws + (i_) - n_visit) : w1)
+  // the window cannot contain a candidate: no reference of it has enough trigrams
+#define BLURRILY_SKIPPABLE(w_) \
+  ((w_) < w1 && min(tc, A.win_max_tri[w_]) < matches_needed(ctl->thr, tc, (w_) * kWindowRanks))
+
+  BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(0u), ca0, cb0, ca1, cb1);
+  BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(1u), na0, nb0, na1, nb1);
   BLURRILY_LOAD_HEAD(ca0, cb0, ca1, cb1);
 
   PHASE_DECL;
-  for (uint32_t w = w0; w < nwin; ++w) {
+  for (uint32_t i = 0; i < n_visit; ++i) {
+    const uint32_t w = BLURRILY_WIN_AT(i);
     const uint32_t wbase = w * kWindowRanks;
     const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
     const bool any = head_any, more = head_more;
@@ -522,8 +539,14 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
       __syncthreads();                                          // counts visible
       PHASE_MARK(3);                                            // barrier after count
     }
-    // keep the memory pipe busy during the scan: head of window w+1 (nxt is all-empty past the end)
-    BLURRILY_LOAD_HEAD(na0, nb0, na1, nb1);
+    // keep the memory pipe busy during the scan: head of the next window (all-empty past the
+    // end); none at all if that window cannot hold a candidate (uniform: thr only changes
+    // behind the barriers of select)
+    if (BLURRILY_SKIPPABLE(BLURRILY_WIN_AT(i + 1))) {
+      head_any = false; head_more = false;
+    } else {
+      BLURRILY_LOAD_HEAD(na0, nb0, na1, nb1);
+    }
     PHASE_MARK(4);                                              // next head issued
     if (any) {
       for (;;) {
@@ -531,16 +554,18 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
         PHASE_MARK(5);                                          // scan
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
-        if (!select_after_scan<NT>(A, pool, ctl, wbase)) break;
+        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
         count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u);   // overflow: again
         __syncthreads();
       }
       PHASE_MARK(7);                                            // select / compaction
     }
     ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
-    BLURRILY_FETCH_TABLE(w + 2, na0, nb0, na1, nb1);
+    BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(i + 2), na0, nb0, na1, nb1);
   }
   PHASE_FLUSH(A);
+#undef BLURRILY_SKIPPABLE
+#undef BLURRILY_WIN_AT
 #undef BLURRILY_LOAD_HEAD
 #undef BLURRILY_FETCH_TABLE
 }
@@ -593,6 +618,11 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
       continue;
     }
     const uint16_t* codes = A.qcodes + A.offsets[q] + q;
+    // the sweep starts at the window of the needle's own length class (inside this task's range)
+    // -- worth it only when there are enough windows for the early threshold to pay back the
+    // ties it forfeits (a window behind the threshold's rank needs one match more)
+    const uint32_t qs = A.q_start[q];
+    const uint32_t ws = (w1 - w0 >= 8 && qs >= w0 && qs < w1) ? qs : w0;
     // results after this key only (later passes of a limit larger than the pool)
     nd.has_floor = A.pass_base != 0;
 
@@ -603,11 +633,11 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     __syncthreads();
 
     if constexpr (SHORT) {
-      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, w0, w1, ws);
     } else if constexpr (sizeof(CT) == 1) {          // byte counters: T <= 127 by construction
-      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1, ws);
     } else {
-      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1);
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1, ws);
       else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, w0, w1);
     }
 
@@ -916,7 +946,8 @@ int launch_tokenise(const TokeniseArgs& t, hipStream_t stream) {
   const uint32_t block = 128;
   const uint32_t grid = (t.n + block - 1) / block;
   hipLaunchKernelGGL(tokenise_kernel, dim3(grid), dim3(block), 0, stream, t.packed, t.offsets, t.n,
-                     t.code_total, t.qcodes, t.q_ntri, t.q_nb, t.big_list, t.big_count, t.mid_list, t.mid_count);
+                     t.code_total, t.qcodes, t.q_ntri, t.q_nb, t.big_list, t.big_count, t.mid_list, t.mid_count,
+                     t.start_win, t.q_start);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }
