@@ -239,7 +239,7 @@ def main():
         info = m.device_info()
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.scale == 1.0:      # measured on the full workload only
             try:
                 traffic = json.load(open(tpath)).get(args.workload)
             except Exception:
