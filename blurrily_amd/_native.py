@@ -26,6 +26,7 @@ class DeviceInfo(C.Structure):
         ("device_ordinal", C.c_int32), ("n_refs", C.c_uint32), ("n_windows", C.c_uint32),
         ("window_bits", C.c_uint32), ("n_entries", C.c_uint64), ("device_bytes", C.c_uint64),
         ("last_find_kernel_ms", C.c_double), ("last_tokenise_kernel_ms", C.c_double),
+        ("n_pending", C.c_uint32), ("n_tombstones", C.c_uint32), ("base_builds", C.c_uint64),
     ]
 
 

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "device_index.h"
@@ -47,9 +49,26 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// Mutations since the base device image was built (DESIGN.md "Mutation and device sync").
+struct PendingPut {
+  std::string needle;
+  uint32_t    weight;
+};
+
 struct trigram_map_t {
   HostIndex*  host = nullptr;
-  DeviceIndex dev;
+  DeviceIndex dev;                      // base image
+  // log of puts/deletes the base image does not contain yet
+  std::unordered_map<uint32_t, PendingPut> pending;   // by reference
+  size_t      n_tomb = 0;               // base references deleted since the build
+  uint64_t    log_version = 0;          // bumped by every logged mutation
+  uint64_t    delta_version = 0;        // log_version the delta image / code totals were built from
+  bool        log_overflow = false;     // the log outgrew its budget: the next find rebuilds the base
+  uint64_t    base_builds = 0;
+  HostIndex*  delta_host = nullptr;
+  DeviceIndex delta;                    // image of `pending` only
+  uint32_t*   d_code_total_now = nullptr;   // [kNumCodes] bucket sizes of the whole map (base run's nb_entries)
+  DeviceBuffer ws_base_rows, ws_base_counts, ws_delta_rows, ws_delta_counts;
   int         n_cus = 0;
   bool        timing = false;
   double      last_find_ms = 0.0, last_tok_ms = 0.0;
@@ -63,14 +82,78 @@ namespace {
 unsigned long long* g_phase_clocks = nullptr;
 #endif
 
+size_t log_budget(const trigram_map m) { return std::max<size_t>(4096, m->dev.n_refs / 64); }
+
+void clear_log(trigram_map m) {
+  m->pending.clear();
+  m->n_tomb = 0;
+  m->log_overflow = false;
+  ++m->log_version;
+  m->delta_version = m->log_version;
+  if (m->delta.device >= 0) device_index_free(&m->delta);
+  delete m->delta_host;
+  m->delta_host = nullptr;
+}
+
+bool log_empty(const trigram_map m) { return m->pending.empty() && m->n_tomb == 0 && !m->log_overflow; }
+
+// Bring the device side up to date with the host index.  Small logs are served by a delta
+// image (built from the pending puts only) plus tombstones on the base image; a log past
+// 1/64 of the base (or 4096 mutations) triggers a full rebuild.
 int ensure_device(trigram_map m) {
-  if (m->dev.device >= 0 && m->dev.built_from == m->host->generation()) return 0;
-  if (device_index_build(*m->host, &m->dev) < 0) return -1;
-  if (m->n_cus == 0) {
-    hipDeviceProp_t prop;
-    BLURRILY_HIP_TRY(hipGetDeviceProperties(&prop, m->dev.device));
-    m->n_cus = prop.multiProcessorCount;
+  const bool have_base = m->dev.device >= 0;
+  if (!have_base || m->log_overflow || m->pending.size() + m->n_tomb > log_budget(m)) {
+    if (device_index_build(*m->host, &m->dev) < 0) return -1;
+    ++m->base_builds;
+    clear_log(m);
+    if (m->n_cus == 0) {
+      hipDeviceProp_t prop;
+      BLURRILY_HIP_TRY(hipGetDeviceProperties(&prop, m->dev.device));
+      m->n_cus = prop.multiProcessorCount;
+    }
+    return 0;
   }
+  if (log_empty(m) || m->delta_version == m->log_version) return 0;
+  // rebuild the delta image and refresh the whole-map bucket sizes
+  delete m->delta_host;
+  m->delta_host = new HostIndex();
+  for (const auto& kv : m->pending)
+    m->delta_host->put(kv.second.needle.data(), kv.second.needle.size(), kv.first, kv.second.weight);
+  if (device_index_build(*m->delta_host, &m->delta) < 0) return -1;
+  std::vector<uint32_t> totals(kNumCodes);
+  for (uint32_t t = 0; t < kNumCodes; ++t) totals[t] = m->host->bucket(t).used;
+  if (!m->d_code_total_now)
+    BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_code_total_now), kNumCodes * sizeof(uint32_t)));
+  BLURRILY_HIP_TRY(hipMemcpy(m->d_code_total_now, totals.data(), kNumCodes * sizeof(uint32_t), hipMemcpyHostToDevice));
+  m->delta_version = m->log_version;
+  return 0;
+}
+
+// Host side of put/delete after the base image exists: log what the image is missing.
+void log_put(trigram_map m, const char* needle, size_t len, uint32_t ref, uint32_t weight) {
+  if (m->dev.device < 0 || m->log_overflow) return;    // no image yet / rebuild pending: nothing to track
+  if (m->pending.size() >= log_budget(m)) {            // bulk import: stop logging, rebuild at the next find
+    m->pending.clear();
+    m->log_overflow = true;
+    return;
+  }
+  m->pending[ref] = PendingPut{std::string(needle, len), weight};
+  ++m->log_version;
+}
+
+int log_delete(trigram_map m, uint32_t ref) {
+  if (m->dev.device < 0 || m->log_overflow) return 0;
+  ++m->log_version;
+  if (m->pending.erase(ref)) return 0;                 // never reached the base image
+  const int64_t rk = device_index_rank_of(m->dev, ref);
+  if (rk < 0) return 0;
+  // set the tombstone bit on the device (stream-ordered with later finds on the default stream)
+  uint32_t word = 0;
+  uint32_t* d_word = m->dev.d_tomb + (rk >> 5);
+  BLURRILY_HIP_TRY(hipMemcpy(&word, d_word, sizeof(word), hipMemcpyDeviceToHost));
+  word |= 1u << (rk & 31);
+  BLURRILY_HIP_TRY(hipMemcpy(d_word, &word, sizeof(word), hipMemcpyHostToDevice));
+  ++m->n_tomb;
   return 0;
 }
 
@@ -90,12 +173,12 @@ bool use_block_mode() {
 }
 
 // Enqueue tokenise + find for n device-resident needles.
-int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
-             uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long,
-             bool maybe_mid, hipStream_t stream) {
+int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_total, const uint32_t* d_tomb,
+                const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n, uint16_t limit,
+                trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long, bool maybe_mid,
+                hipStream_t stream) {
   if (n == 0) return 0;
   if (n > 0xFFFFFFF0ull) { errno = EINVAL; return -1; }
-  const DeviceIndex& ix = m->dev;
 
   // scratch: codes | per-needle arrays | scalars
   const size_t code_slots = packed_bytes + n;
@@ -117,7 +200,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   BLURRILY_HIP_TRY(hipMemsetAsync(scalars, 0, 256, stream));
 
   if (m->timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev[0], stream));
-  TokeniseArgs t{d_packed, d_offsets, uint32_t(n), ix.d_code_total, static_cast<uint16_t*>(m->ws_codes.p),
+  TokeniseArgs t{d_packed, d_offsets, uint32_t(n), d_code_total, static_cast<uint16_t*>(m->ws_codes.p),
                  q_ntri, q_nb, big_list, scalars, mid_list, scalars + 1, ix.d_start_win, q_start};
   if (launch_tokenise(t, stream) < 0) return -1;
   if (m->timing) {
@@ -131,6 +214,7 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   a.offsets = d_offsets; a.qcodes = static_cast<const uint16_t*>(m->ws_codes.p);
   a.q_ntri = q_ntri; a.q_nb = q_nb; a.q_start = q_start; a.win_max_tri = ix.d_win_max_tri; a.results = d_results; a.counts = d_counts; a.limit = limit;
   a.floor = floor;
+  a.tomb = d_tomb;
 #ifdef BLURRILY_PHASE_PROFILE
   {
     static unsigned long long* d_phase = nullptr;
@@ -246,6 +330,35 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   return 0;
 }
 
+// Enqueue tokenise + find for n device-resident needles on the map's current contents.
+int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
+             uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long,
+             bool maybe_mid, hipStream_t stream) {
+  if (log_empty(m))
+    return run_find_on(m, m->dev, m->dev.d_code_total, nullptr, d_packed, packed_bytes, d_offsets, n, limit,
+                       d_results, d_counts, d_nb, maybe_long, maybe_mid, stream);
+  // base image (minus tombstones) and delta image hold disjoint references: find on both, merge
+  const size_t row_bytes = std::max<size_t>(n * size_t(limit) * sizeof(trigram_match_t), 16);
+  if (m->ws_base_rows.reserve(row_bytes, stream) < 0 || m->ws_base_counts.reserve(n * 4, stream) < 0 ||
+      m->ws_delta_rows.reserve(row_bytes, stream) < 0 || m->ws_delta_counts.reserve(n * 4, stream) < 0)
+    return -1;
+  trigram_match base_rows = static_cast<trigram_match>(m->ws_base_rows.p);
+  uint32_t* base_counts = static_cast<uint32_t*>(m->ws_base_counts.p);
+  trigram_match delta_rows = static_cast<trigram_match>(m->ws_delta_rows.p);
+  uint32_t* delta_counts = static_cast<uint32_t*>(m->ws_delta_counts.p);
+  if (run_find_on(m, m->dev, m->d_code_total_now, m->n_tomb ? m->dev.d_tomb : nullptr, d_packed, packed_bytes,
+                  d_offsets, n, limit, base_rows, base_counts, d_nb, maybe_long, maybe_mid, stream) < 0)
+    return -1;
+  if (m->pending.empty()) {
+    BLURRILY_HIP_TRY(hipMemsetAsync(delta_counts, 0, n * 4, stream));
+  } else if (run_find_on(m, m->delta, m->delta.d_code_total, nullptr, d_packed, packed_bytes, d_offsets, n, limit,
+                         delta_rows, delta_counts, nullptr, maybe_long, maybe_mid, stream) < 0) {
+    return -1;
+  }
+  return launch_merge_rows(base_rows, base_counts, delta_rows, delta_counts, uint32_t(n), limit, d_results,
+                           d_counts, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -276,6 +389,10 @@ int blurrily_storage_close(trigram_map* haystack) {
       (void)hipDeviceSynchronize();
       device_index_free(&m->dev);
     }
+    if (m->delta.device >= 0) device_index_free(&m->delta);
+    delete m->delta_host;
+    if (m->d_code_total_now) (void)hipFree(m->d_code_total_now);
+    m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_packed.release();
     m->ws_io_offsets.release(); m->ws_io_results.release(); m->ws_io_counts.release();
@@ -291,7 +408,10 @@ void blurrily_storage_mark(trigram_map) {}
 int blurrily_storage_save(trigram_map haystack, const char* path) { return haystack->host->save(path); }
 
 int blurrily_storage_put(trigram_map haystack, const char* needle, uint32_t reference, uint32_t weight) {
-  return haystack->host->put(needle, std::strlen(needle), reference, weight);
+  const size_t len = std::strlen(needle);
+  const int added = haystack->host->put(needle, len, reference, weight);
+  if (added > 0) log_put(haystack, needle, len, reference, weight);
+  return added;
 }
 
 long blurrily_storage_put_many(trigram_map haystack, const char* packed, const uint64_t* offsets,
@@ -302,12 +422,18 @@ long blurrily_storage_put_many(trigram_map haystack, const char* packed, const u
     const size_t cap = size_t(offsets[i + 1] - offsets[i]);
     const void* nul = std::memchr(s, 0, cap);
     const size_t len = nul ? size_t(static_cast<const char*>(nul) - s) : cap;
-    total += haystack->host->put(s, len, references[i], weights ? weights[i] : 0u);
+    const int added = haystack->host->put(s, len, references[i], weights ? weights[i] : 0u);
+    if (added > 0) log_put(haystack, s, len, references[i], weights ? weights[i] : 0u);
+    total += added;
   }
   return total;
 }
 
-int blurrily_storage_delete(trigram_map haystack, uint32_t reference) { return haystack->host->del(reference); }
+int blurrily_storage_delete(trigram_map haystack, uint32_t reference) {
+  const int removed = haystack->host->del(reference);
+  if (removed > 0 && log_delete(haystack, reference) < 0) return -1;
+  return removed;
+}
 
 int blurrily_storage_stats(trigram_map haystack, trigram_stat_t* stats) {
   stats->references = haystack->host->total_refs();
@@ -404,6 +530,9 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
   info->device_bytes = m->dev.device_bytes;
   info->last_find_kernel_ms = m->last_find_ms;
   info->last_tokenise_kernel_ms = m->last_tok_ms;
+  info->n_pending = uint32_t(m->pending.size());
+  info->n_tombstones = uint32_t(m->n_tomb);
+  info->base_builds = m->base_builds;
   return 0;
 }
 

@@ -33,6 +33,7 @@
 // reference's 8 bytes.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "host_index.h"
 
@@ -62,6 +63,10 @@ struct DeviceIndex {
   uint32_t* d_code_total     = nullptr;   // [kNumCodes]
   uint32_t* d_win_max_tri    = nullptr;   // [n_windows] most postings any one reference of the window has
   uint32_t* d_start_win      = nullptr;   // [256] window holding the first rank whose weight is >= the index
+  uint32_t* d_tomb           = nullptr;   // [(n_refs+31)/32] bit r: rank r was deleted after the build
+  // host copies for mapping a reference to its rank (deletes after the build)
+  std::vector<uint32_t> h_sorted_ref;     // references ascending
+  std::vector<uint32_t> h_rank_of_pos;    // rank of h_sorted_ref[i]
 };
 
 // Build the device image of `host` on the current HIP device.  Returns 0, or
@@ -71,5 +76,7 @@ struct DeviceIndex {
 // buckets).
 int  device_index_build(const HostIndex& host, DeviceIndex* out);
 void device_index_free(DeviceIndex* ix);
+// Rank of `ref` in the device image, or -1 if the image does not hold it.
+int64_t device_index_rank_of(const DeviceIndex& ix, uint32_t ref);
 
 }  // namespace blurrily

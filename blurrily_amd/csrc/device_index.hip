@@ -50,6 +50,7 @@ void device_index_free(DeviceIndex* ix) {
   if (ix->d_code_total)     (void)hipFree(ix->d_code_total);
   if (ix->d_win_max_tri)    (void)hipFree(ix->d_win_max_tri);
   if (ix->d_start_win)      (void)hipFree(ix->d_start_win);
+  if (ix->d_tomb)           (void)hipFree(ix->d_tomb);
   *ix = DeviceIndex();
 }
 
@@ -250,7 +251,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   DeviceIndex ix;
   ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz; ix.n_slots = n_slots;
   ix.built_from = host.generation();
-  auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {
+  auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {   // v may be a temporary
     using T = typename std::remove_reference<decltype(v)>::type::value_type;
     const size_t bytes = std::max(v.size(), min_elems) * sizeof(T);
     BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), bytes));
@@ -260,15 +261,24 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   };
   if (up(&ix.d_ref_of_rank, ref_of_rank, 1) || up(&ix.d_weight_of_rank, weight_of_rank, 1) ||
       up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
-      up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1)) {
+      up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1) ||
+      up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1)) {
     const int e = errno;
     device_index_free(&ix);
     errno = e;
     return -1;
   }
+  ix.h_sorted_ref.swap(sorted_ref);
+  ix.h_rank_of_pos.swap(rank_of_pos);
   device_index_free(out);
-  *out = ix;
+  *out = std::move(ix);
   return 0;
+}
+
+int64_t device_index_rank_of(const DeviceIndex& ix, uint32_t ref) {
+  const auto it = std::lower_bound(ix.h_sorted_ref.begin(), ix.h_sorted_ref.end(), ref);
+  if (it == ix.h_sorted_ref.end() || *it != ref) return -1;
+  return ix.h_rank_of_pos[size_t(it - ix.h_sorted_ref.begin())];
 }
 
 }  // namespace blurrily

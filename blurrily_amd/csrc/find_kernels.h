@@ -41,6 +41,7 @@ struct FindArgs {
   const uint32_t* q_nb;
   const uint32_t* q_start;     // [n] window the sweep starts at (the needle's own length class)
   const uint32_t* win_max_tri; // [n_windows] match-count bound per window
+  const uint32_t* tomb;        // bit r set: rank r was deleted after the image was built (nullptr: none)
   const uint32_t* work_list;   // nullptr: slots are needle ids, long needles skipped
   const uint32_t* n_work_dev;  // when set, the number of slots is read from the device
   uint32_t        n_work;
@@ -71,5 +72,10 @@ int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t
 uint32_t find_block_size(uint32_t keep, uint32_t* mini_cap);
 int launch_find_block(const FindArgs& a, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
+// Merge, per needle, two result lists that are each in result order (base image and delta image
+// hold disjoint references) into the first `limit` rows of `out`.
+int launch_merge_rows(const trigram_match_t* a_rows, const uint32_t* a_counts, const trigram_match_t* b_rows,
+                      const uint32_t* b_counts, uint32_t n, uint32_t limit, trigram_match_t* out,
+                      uint32_t* out_counts, hipStream_t stream);
 
 }  // namespace blurrily

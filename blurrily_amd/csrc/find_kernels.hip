@@ -242,9 +242,9 @@ __device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint3
 // ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
-                                          const unsigned long long* floor, unsigned long long* pool,
-                                          const uint32_t pool_cap, uint32_t* pool_n, uint32_t* overflow,
-                                          uint32_t wbase, uint32_t wlen) {
+                                          const unsigned long long* floor, const uint32_t* tomb,
+                                          unsigned long long* pool, const uint32_t pool_cap, uint32_t* pool_n,
+                                          uint32_t* overflow, uint32_t wbase, uint32_t wlen) {
   using P = Packing<CT>;
   constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
   const uint32_t tid = threadIdx.x;
@@ -265,6 +265,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
           const unsigned long long key = (static_cast<unsigned long long>(nd.T - cnt) << 32) | rank;
           bool pass = key <= thr;
           if (nd.has_floor) pass = pass && key > *floor;
+          if (tomb) pass = pass && ((tomb[rank >> 5] >> (rank & 31)) & 1u) == 0;   // deleted since the build
           if (pass) {
             const uint32_t at = atomicAdd(pool_n, 1u);
             if (at < pool_cap) pool[at] = key;
@@ -305,8 +306,8 @@ template <typename CT, int NT>
 __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd, uint4* cnt128,
                                             unsigned long long* pool, Control* ctl, uint32_t wbase,
                                             uint32_t wlen) {
-  scan_core<CT, NT>(cnt128, nd, ctl->thr, &ctl->floor, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow, wbase,
-                    wlen);
+  scan_core<CT, NT>(cnt128, nd, ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow,
+                    wbase, wlen);
 }
 
 // ---- select: keep the pool small and the threshold tight.  Returns true when the pool
@@ -704,6 +705,35 @@ __global__ __launch_bounds__(NT) void merge_parts_kernel(const FindArgs A) {
   if (tid == 0) A.counts[q] = nres;
 }
 
+// ---- base + delta: merge two per-needle result lists in result order ----------------------
+// (matches descending, weight ascending, reference ascending; the two images hold disjoint
+// references, so the first `limit` rows of the merge are the answer).  One lane per needle.
+__global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, const uint32_t* __restrict__ a_counts,
+                                  const trigram_match_t* __restrict__ b_rows, const uint32_t* __restrict__ b_counts,
+                                  uint32_t n, uint32_t limit, trigram_match_t* __restrict__ out,
+                                  uint32_t* __restrict__ out_counts) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const trigram_match_t* a = a_rows + size_t(q) * limit;
+  const trigram_match_t* b = b_rows + size_t(q) * limit;
+  trigram_match_t* o = out + size_t(q) * limit;
+  const uint32_t na = a_counts[q], nb = b_counts[q];
+  uint32_t i = 0, j = 0, k = 0;
+  while (k < limit && (i < na || j < nb)) {
+    bool take_a;
+    if (i >= na) take_a = false;
+    else if (j >= nb) take_a = true;
+    else {
+      const trigram_match_t x = a[i], y = b[j];
+      if (x.matches != y.matches) take_a = x.matches > y.matches;
+      else if (x.weight != y.weight) take_a = x.weight < y.weight;
+      else take_a = x.reference < y.reference;
+    }
+    o[k++] = take_a ? a[i++] : b[j++];
+  }
+  out_counts[q] = k;
+}
+
 // =============================================================================================
 // Block sweep: one workgroup owns a block of up to 64 needles and sweeps window-major -- for
 // each window, for each needle of the block -- so that the hot slices of a window are read
@@ -862,8 +892,8 @@ __global__ __launch_bounds__(NT, 8) void find_block_kernel(const FindArgs A) {
         if (any) {
           Needle nd; nd.T = meta[qi].T; nd.has_floor = false;
           for (;;) {
-            scan_core<CT, NT>(cnt128, nd, meta[qi].thr, nullptr, pool, MP, &meta[qi].count, &ctl->overflow,
-                              wbase, wlen);
+            scan_core<CT, NT>(cnt128, nd, meta[qi].thr, nullptr, A.tomb, pool, MP, &meta[qi].count,
+                              &ctl->overflow, wbase, wlen);
             __syncthreads();                                    // counters are zero again
             if (!ctl->overflow) {
               // a filling pool is compacted by one wave while the others move on: the needle's
@@ -995,6 +1025,16 @@ int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) 
     attr_done = true;
   }
   hipLaunchKernelGGL((merge_parts_kernel<NT>), dim3(n_items), dim3(NT), lds, stream, a);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_merge_rows(const trigram_match_t* a_rows, const uint32_t* a_counts, const trigram_match_t* b_rows,
+                      const uint32_t* b_counts, uint32_t n, uint32_t limit, trigram_match_t* out,
+                      uint32_t* out_counts, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(merge_rows_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, a_rows, a_counts, b_rows,
+                     b_counts, n, limit, out, out_counts);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }

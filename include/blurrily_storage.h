@@ -134,6 +134,9 @@ typedef struct blurrily_device_info_t {
   uint64_t device_bytes;        /* HBM bytes held by the index                   */
   double   last_find_kernel_ms; /* HIP-event time of the last find kernel launch */
   double   last_tokenise_kernel_ms;
+  uint32_t n_pending;           /* puts since the base image was built (served by a delta image) */
+  uint32_t n_tombstones;        /* base references deleted since the build                       */
+  uint64_t base_builds;         /* full device-image builds so far                               */
 } blurrily_device_info_t;
 int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* info);
 

@@ -167,3 +167,51 @@ def test_arbitrary_bytes_needles():
     m, o = build_pair(W.unpack(hay, off))
     needles = [b"Lond\xc3\xa9n", b"a*b c", b"***", b"  ", b"UPPER lower", bytes(range(1, 60))]
     _check_batch(m, o, needles, 10)
+
+
+def test_interleaved_mutations_are_served_by_delta_image_and_tombstones():
+    """put/delete after the device image exists (storage.c:398-473, :584-612 semantics): small
+    logs must not trigger a rebuild, and results stay bit-exact -- including a reference that
+    is deleted and put again with another string."""
+    rng = np.random.default_rng(21)
+    hay, off = W.words(60000, seed=31)
+    strings = W.unpack(hay, off)
+    m, o = RawMap(), Oracle()
+    refs = np.arange(1, len(strings) + 1, dtype=np.uint32)
+    m.put_many_packed(hay, off, refs)
+    o.put_many(hay, off)
+    q, qo = W.queries(hay, off, 120, seed=32)
+    needles = W.unpack(q, qo)
+    _check_batch(m, o, needles, 10)
+    assert m.device_info()["base_builds"] == 1
+    extra, eo = W.words(4000, seed=33)
+    extra = W.unpack(extra, eo)
+    m2, o2 = m, o
+    live = set(int(r) for r in refs)
+    used_extra = 0
+    for rnd in range(10):
+        for _ in range(30):
+            r = int(rng.choice(sorted(live)))
+            assert m2.delete(r) == o2.delete(r) > 0
+            live.discard(r)
+        for _ in range(50):
+            s = extra[used_extra]; used_extra += 1
+            r = (10**6 + used_extra) if rng.random() < 0.7 else int(rng.integers(1, 60001))
+            w = int(rng.integers(0, 3))
+            a = m2.put(s, r, w)
+            assert a == o2.put(s, r, w)
+            if a:
+                live.add(r)
+        assert m2.stats() == o2.stats()
+        _check_batch(m2, o2, needles + extra[:used_extra][-20:], 10)
+        _check_batch(m2, o2, needles[:10], 100)
+    info = m2.device_info()
+    assert info["base_builds"] == 1 and info["n_pending"] > 0 and info["n_tombstones"] > 0
+    # a log past its budget folds into a rebuilt base image
+    big, bo = W.words(9000, seed=34)
+    m2.put_many_packed(big, bo, np.arange(2 * 10**6, 2 * 10**6 + 9000, dtype=np.uint32))
+    for i, s in enumerate(W.unpack(big, bo)):
+        o2.put(s, 2 * 10**6 + i, 0)
+    _check_batch(m2, o2, needles[:40], 10)
+    info = m2.device_info()
+    assert info["base_builds"] == 2 and info["n_pending"] == 0 and info["n_tombstones"] == 0
