@@ -160,6 +160,7 @@ struct Control {            // workgroup-shared scalars
   uint32_t pool_n;
   uint32_t overflow;
   uint32_t q;
+  uint32_t tally;           // scratch of cold_start_need
 };
 
 template <typename CT>
@@ -244,11 +245,12 @@ template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
                                           const unsigned long long* floor, const uint32_t* tomb,
                                           unsigned long long* pool, const uint32_t pool_cap, uint32_t* pool_n,
-                                          uint32_t* overflow, uint32_t wbase, uint32_t wlen) {
+                                          uint32_t* overflow, uint32_t wbase, uint32_t wlen,
+                                          const uint32_t need_floor = 0) {
   using P = Packing<CT>;
   constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
   const uint32_t tid = threadIdx.x;
-  const uint32_t need = matches_needed(thr, nd.T, wbase);
+  const uint32_t need = max(matches_needed(thr, nd.T, wbase), need_floor);
   const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
   if (need <= nd.T) {
     const uint32_t bias = (P::kTop - need) * P::kOnes;
@@ -302,12 +304,52 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
   if (nvec < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
 }
 
+// Cold start: with no threshold yet, every non-zero counter of a window would flood the pool
+// (overflow, sort, sweep again -- several times).  Instead find, by bisection over the counter
+// value, the largest c such that at least `keep` counters of THIS window reach c: those alone
+// already fill the answer, so counters below c cannot be part of it and the first scan admits
+// only counters >= c.  A pass reads the counters (no clearing) and tallies the SWAR hits.
+template <typename CT, int NT>
+__device__ __forceinline__ uint32_t cold_start_need(const uint4* cnt128, uint32_t T, uint32_t keep, Control* ctl,
+                                                    uint32_t wlen) {
+  using P = Packing<CT>;
+  constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
+  uint32_t lo = 1, hi = T;                               // answer in [lo, hi]; lo = 1 means "no restriction"
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (tid == 0) ctl->tally = 0;
+    __syncthreads();
+    const uint32_t bias = (P::kTop - mid) * P::kOnes;
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < nvec; i += NT) {
+      uint4 v = cnt128[i];
+      if (i == kVecs - 1) v.w &= ~(P::kMask << (32 - P::kBits));    // slot 0xFFFF counts padding
+      mine += __popc((v.x + bias) & P::kHi) + __popc((v.y + bias) & P::kHi) +
+              __popc((v.z + bias) & P::kHi) + __popc((v.w + bias) & P::kHi);
+    }
+#pragma unroll
+    for (uint32_t d = 32; d; d >>= 1) mine += __shfl_xor(mine, int(d));
+    if (lane == 0 && mine) atomicAdd(&ctl->tally, mine);
+    __syncthreads();
+    if (ctl->tally >= keep) lo = mid; else hi = mid - 1;
+    __syncthreads();                                     // tally read by everyone before it is reset
+  }
+  return lo;
+}
+
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd, uint4* cnt128,
                                             unsigned long long* pool, Control* ctl, uint32_t wbase,
                                             uint32_t wlen) {
-  scan_core<CT, NT>(cnt128, nd, ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow,
-                    wbase, wlen);
+  const unsigned long long thr = ctl->thr;
+  uint32_t need_floor = 0;
+  // (not with a floor key or tombstones: candidates they reject would be counted as present)
+  if (thr == kKeyInf && !nd.has_floor && !A.tomb && nd.T > 1)
+    need_floor = cold_start_need<CT, NT>(cnt128, nd.T, A.keep, ctl, wlen);
+  scan_core<CT, NT>(cnt128, nd, thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow,
+                    wbase, wlen, need_floor);
 }
 
 // ---- select: keep the pool small and the threshold tight.  Returns true when the pool
@@ -317,7 +359,9 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
                                                   uint32_t wbase, uint32_t wlen) {
   const uint32_t ov = ctl->overflow;
   const uint32_t pn = ctl->pool_n;
-  if (!(ov || pn > A.pool_cap / 2)) return false;
+  // compact when the pool fills up -- or as soon as it holds `keep` candidates for the first
+  // time, so that a threshold exists from then on
+  if (!(ov || pn > A.pool_cap / 2 || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
   compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
   if (!ov) return false;
   // The pool overflowed mid-window: candidates of this window were lost.  Keep the
@@ -633,14 +677,32 @@ __global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
     }
     __syncthreads();
 
-    if constexpr (SHORT) {
-      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, w0, w1, ws);
-    } else if constexpr (sizeof(CT) == 1) {          // byte counters: T <= 127 by construction
-      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1, ws);
-    } else {
-      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, w0, w1, ws);
-      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, w0, w1);
+    // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
+#define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
+  do {                                                                                                  \
+    if constexpr (SHORT) {                                                                              \
+      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
+    } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
+      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_);                 \
+    } else {                                                                                            \
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
+      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, a_, b_);     \
+    }                                                                                                   \
+  } while (0)
+    if constexpr (RANGED) {
+      // A range that does not contain the needle's own length class first sweeps that window
+      // only to learn a threshold (the keep-th best of real candidates bounds the answer), then
+      // forgets those candidates -- the range that owns the window reports them -- and sweeps
+      // its own windows with few admissions instead of a cold start.
+      if (qs < A.n_windows && !(qs >= w0 && qs < w1)) {
+        BLURRILY_SWEEP(qs, qs + 1, qs);
+        compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+        if (tid == 0) ctl->pool_n = 0;
+        __syncthreads();
+      }
     }
+    BLURRILY_SWEEP(w0, w1, ws);
+#undef BLURRILY_SWEEP
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
     compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
