@@ -215,3 +215,42 @@ def test_interleaved_mutations_are_served_by_delta_image_and_tombstones():
     _check_batch(m2, o2, needles[:40], 10)
     info = m2.device_info()
     assert info["base_builds"] == 2 and info["n_pending"] == 0 and info["n_tombstones"] == 0
+
+
+def test_value_range_edges():
+    """Extremes of the reference's validated ranges (lib/blurrily/defaults.rb:7-9): reference 0
+    and 2^31-1, weights up to 2^31-1, strings that are empty or all non-letters, limit 0 and the
+    largest uint16_t limit, a needle cut at an embedded NUL."""
+    strings = [b"", b"   ", b"a", b"zz", b"london", b"london", b"londres", b"l", b"***", b"lon don"]
+    refs = [0, 1, 2, 2**31 - 1, 77, 78, 2**30, 5, 6, 7]
+    weights = [0, 2**31 - 1, 1, 0, 2**31 - 1, 1, 0, 0, 3, 2]
+    m, o = build_pair(strings, refs, weights)
+    needles = [b"", b"london", b"lon", b"l", b"zz", b"a", b" ", b"don lon", b"londonlondon"]
+    for limit in (1, 2, 10, 65535):
+        _check_batch(m, o, needles, limit)
+    # limit 0 (storage.c:569: min(0, nb_matches)) through the C ABI
+    rows = (np.zeros((4, 3), dtype=np.uint32))
+    assert m._lib.blurrily_storage_find(m.handle, b"london", 0, rows.ctypes.data) == 0
+    # a batched needle is cut at its first NUL, like the C string the reference sees
+    packed = np.frombuffer(b"london\0garbage" + b"lon", dtype=np.uint8)
+    off = np.array([0, 14, 17], dtype=np.uint64)
+    got, counts = m.find_batch_packed(packed, off, 10)
+    assert got[0, :counts[0]].tolist() == o.find(b"london", 10)
+    assert got[1, :counts[1]].tolist() == o.find(b"lon", 10)
+
+
+def test_very_long_needles_and_haystack_strings():
+    """Thousands of distinct trigrams in one needle (16-bit counters, staged slice table) against a
+    haystack that also holds very long strings."""
+    rng = np.random.default_rng(8)
+    hay, off = W.geonames(30000, 4000, seed=13)
+    strings = W.unpack(hay, off)
+    long_strings = [b" ".join(strings[i:i + 300]) for i in range(0, 3000, 300)]       # ~4000 chars each
+    all_strings = strings + long_strings
+    m, o = build_pair(all_strings)
+    needles = [long_strings[0], long_strings[3][:1500], b" ".join(strings[5000:5400]),
+               bytes(rng.choice(np.frombuffer(b"abcdefghijklmnopqrstuvwxyz ", dtype=np.uint8), size=6000).tolist()),
+               strings[10], b"x" * 5000]
+    assert max(len(Oracle.tokenise(nd)) for nd in needles) > 1000
+    _check_batch(m, o, needles, 10)
+    _check_batch(m, o, needles[:3], 700)
