@@ -88,3 +88,26 @@ def test_full_geonames_scale_properties():
     o.put_many(hay, off)
     for nd, rows in list(zip(needles, got))[1990:2030]:
         assert rows == o.find(nd, limit), nd
+
+
+def test_full_skewed_scale_properties():
+    """configs[4] haystack (4 000 000 hot-trigram strings, limit 100): massive (matches, weight)
+    ties; order, uniqueness and idempotence on every row, a sample row for row against the oracle."""
+    n = 4_000_000
+    hay, off = W.skewed(n, 5)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    q, qo = W.queries(hay, off, 1500, 55)
+    needles = W.unpack(q, qo)
+    limit = 100
+    got = _batch(m, needles, limit)
+    assert got == _batch(m, needles, limit)
+    for nd, rows in zip(needles, got):
+        T = len(Oracle.tokenise(nd))
+        keys = [(-r[1], r[2], r[0]) for r in rows]
+        assert keys == sorted(keys) and len(set(r[0] for r in rows)) == len(rows) and len(rows) <= limit
+        assert all(1 <= r[1] <= T for r in rows)
+    o = Oracle()
+    o.put_many(hay, off)
+    for nd, rows in list(zip(needles, got))[:24]:
+        assert rows == o.find(nd, limit), nd
