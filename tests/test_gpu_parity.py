@@ -254,3 +254,20 @@ def test_very_long_needles_and_haystack_strings():
     assert max(len(Oracle.tokenise(nd)) for nd in needles) > 1000
     _check_batch(m, o, needles, 10)
     _check_batch(m, o, needles[:3], 700)
+
+
+@pytest.mark.parametrize("n", [65534, 65535, 65536, 131070, 131071])
+def test_window_boundaries_and_cross_window_ties(n):
+    """Haystack sizes around the 65 535-rank window: every string ties with every other on
+    (matches, weight), so the order is purely reference-ascending across window boundaries,
+    including limits that cross a window and the multi-pass path."""
+    m, o = RawMap(), Oracle()
+    strings = [b"london"] * n
+    refs = np.arange(1, n + 1, dtype=np.uint32)
+    packed = np.frombuffer(b"".join(strings), dtype=np.uint8)
+    off = (np.arange(n + 1, dtype=np.uint64) * 6)
+    m.put_many_packed(packed, off, refs)
+    o.put_many(packed, off, refs)
+    m.put("paris", n + 10, 0); o.put(b"paris", n + 10, 0)          # lives alone at the end of the ranks
+    for limit in (1, 10, 1024, 1025, 65535):
+        _check_batch(m, o, [b"london", b"londno", b"paris", b"pa"], limit)
