@@ -73,7 +73,8 @@ struct trigram_map_t {
   bool        timing = false;
   double      last_find_ms = 0.0, last_tok_ms = 0.0;
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_packed, ws_io_offsets, ws_io_results, ws_io_counts;
+  DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_in, ws_io_out;
+  unsigned char* h_stage = nullptr;     // pinned host staging: [kStageBytes in | kStageBytes out]
 };
 
 namespace {
@@ -158,6 +159,7 @@ int log_delete(trigram_map m, uint32_t ref) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for small host-buffer batches
 
 // BLURRILY_FIND_MODE=block opts into the experimental block sweep (find_block_kernel: a
 // workgroup sweeps a block of needles window-major).  Measured on MI355X it matches the
@@ -275,9 +277,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       a.part_count = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(m->ws_parts.p) + key_bytes);
       a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-      // needles with > 127 distinct trigrams are skipped by the byte-counter kernel: their
-      // tasks must not leave stale counts behind for the merge
-      BLURRILY_HIP_TRY(hipMemsetAsync(a.part_count, 0, tasks * 4, stream));
+      // (every task writes its part_count, also the ones the byte-counter kernel skips)
       a.short_only = 1;
       if (launch_find(a, false, uint32_t(std::min<size_t>(tasks, wgs)), stream) < 0) return -1;
       uint32_t merge_cap = 1024;
@@ -394,8 +394,9 @@ int blurrily_storage_close(trigram_map* haystack) {
     if (m->d_code_total_now) (void)hipFree(m->d_code_total_now);
     m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
-    m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_packed.release();
-    m->ws_io_offsets.release(); m->ws_io_results.release(); m->ws_io_counts.release();
+    m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
+    m->ws_io_out.release();
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
     delete m->host;
     delete m;
   }
@@ -486,25 +487,49 @@ int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_
 
   hipStream_t stream = nullptr;
   const size_t packed_bytes = size_t(offsets[n]);
-  if (m->ws_io_packed.reserve(std::max<size_t>(packed_bytes, 16), stream) < 0 ||
-      m->ws_io_offsets.reserve((n + 1) * sizeof(uint64_t), stream) < 0 ||
-      m->ws_io_results.reserve(std::max<size_t>(n * size_t(limit) * sizeof(trigram_match_t), 16), stream) < 0 ||
-      m->ws_io_counts.reserve(n * sizeof(uint32_t), stream) < 0)
+  const size_t off_bytes = (n + 1) * sizeof(uint64_t);
+  const size_t row_bytes = n * size_t(limit) * sizeof(trigram_match_t);
+  const size_t cnt_bytes = n * sizeof(uint32_t);
+  // one device block in ([offsets | needles]) and one out ([counts | rows])
+  const size_t in_bytes = align_up(off_bytes, 256) + std::max<size_t>(packed_bytes, 16);
+  const size_t out_bytes = align_up(cnt_bytes, 256) + std::max<size_t>(row_bytes, 16);
+  if (m->ws_io_in.reserve(in_bytes, stream) < 0 || m->ws_io_out.reserve(out_bytes, stream) < 0) return -1;
+  unsigned char* d_in = static_cast<unsigned char*>(m->ws_io_in.p);
+  unsigned char* d_out = static_cast<unsigned char*>(m->ws_io_out.p);
+  const uint64_t* d_offsets = reinterpret_cast<const uint64_t*>(d_in);
+  const char* d_packed = reinterpret_cast<const char*>(d_in + align_up(off_bytes, 256));
+  uint32_t* d_counts = reinterpret_cast<uint32_t*>(d_out);
+  trigram_match d_rows = reinterpret_cast<trigram_match>(d_out + align_up(cnt_bytes, 256));
+
+  // Small batches (the single blurrily_storage_find above all) go through pinned staging: one
+  // copy in, one copy out, instead of four pageable ones.
+  const bool staged = in_bytes <= kStageBytes && out_bytes <= kStageBytes;
+  if (staged && !m->h_stage) BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->h_stage), 2 * kStageBytes));
+  if (staged) {
+    unsigned char* h_in = m->h_stage;
+    std::memcpy(h_in, offsets, off_bytes);
+    if (packed_bytes) std::memcpy(h_in + align_up(off_bytes, 256), packed, packed_bytes);
+    BLURRILY_HIP_TRY(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, stream));
+  } else {
+    BLURRILY_HIP_TRY(hipMemcpyAsync(d_in, offsets, off_bytes, hipMemcpyHostToDevice, stream));
+    if (packed_bytes)
+      BLURRILY_HIP_TRY(hipMemcpyAsync(d_in + align_up(off_bytes, 256), packed, packed_bytes, hipMemcpyHostToDevice,
+                                      stream));
+  }
+  if (run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_rows, d_counts, nullptr, max_len > 126,
+               max_len > 63, stream) < 0)
     return -1;
-  if (packed_bytes)
-    BLURRILY_HIP_TRY(hipMemcpyAsync(m->ws_io_packed.p, packed, packed_bytes, hipMemcpyHostToDevice, stream));
-  BLURRILY_HIP_TRY(hipMemcpyAsync(m->ws_io_offsets.p, offsets, (n + 1) * sizeof(uint64_t),
-                                  hipMemcpyHostToDevice, stream));
-  if (run_find(m, static_cast<const char*>(m->ws_io_packed.p), packed_bytes,
-               static_cast<const uint64_t*>(m->ws_io_offsets.p), n, limit,
-               static_cast<trigram_match>(m->ws_io_results.p), static_cast<uint32_t*>(m->ws_io_counts.p),
-               nullptr, max_len > 126, max_len > 63, stream) < 0)
-    return -1;
-  BLURRILY_HIP_TRY(hipMemcpyAsync(counts, m->ws_io_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  if (limit)
-    BLURRILY_HIP_TRY(hipMemcpyAsync(results, m->ws_io_results.p, n * size_t(limit) * sizeof(trigram_match_t),
-                                    hipMemcpyDeviceToHost, stream));
-  BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
+  if (staged) {
+    unsigned char* h_out = m->h_stage + kStageBytes;
+    BLURRILY_HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+    BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(counts, h_out, cnt_bytes);
+    if (limit) std::memcpy(results, h_out + align_up(cnt_bytes, 256), row_bytes);
+  } else {
+    BLURRILY_HIP_TRY(hipMemcpyAsync(counts, d_counts, cnt_bytes, hipMemcpyDeviceToHost, stream));
+    if (limit) BLURRILY_HIP_TRY(hipMemcpyAsync(results, d_rows, row_bytes, hipMemcpyDeviceToHost, stream));
+    BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
+  }
   return 0;
 }
 

@@ -89,21 +89,24 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   const uint64_t cap = end - beg;
   while (len < cap && s[len] != 0) ++len;        // a needle is a C string (storage.c:480)
 
-  // frame "**" + s + "*" and encode (tokeniser.c:62-75)
+  // frame "**" + s + "*" and encode (tokeniser.c:62-75); sort ascending (tokeniser.c:93).
+  // Needles of up to 64 codes (nearly all) are sorted in the lane's private LDS row -- an
+  // insertion sort straight in global memory is a chain of dependent round trips.
+  __shared__ uint16_t s_row[128][66];                     // 66: odd word stride, no bank conflicts
   uint32_t a = 0, b = 0;
   const uint64_t m = len + 1;
+  uint16_t* work = (m <= 64) ? s_row[threadIdx.x] : out;
   for (uint64_t k = 0; k < m; ++k) {
     const uint32_t c = (k < len) ? dev_symbol((unsigned char)s[k]) : 0u;
-    out[k] = uint16_t(a + 28u * b + 784u * c);
+    work[k] = uint16_t(a + 28u * b + 784u * c);
     a = b; b = c;
   }
-  // sort ascending (tokeniser.c:93)
   if (m <= 96) {
     for (uint64_t i = 1; i < m; ++i) {
-      const uint16_t v = out[i];
+      const uint16_t v = work[i];
       uint64_t j = i;
-      while (j > 0 && out[j - 1] > v) { out[j] = out[j - 1]; --j; }
-      out[j] = v;
+      while (j > 0 && work[j - 1] > v) { work[j] = work[j - 1]; --j; }
+      work[j] = v;
     }
   } else {
     // heap sort in place for very long needles
@@ -111,24 +114,25 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
       for (;;) {
         uint64_t child = 2 * root + 1;
         if (child >= lim) return;
-        if (child + 1 < lim && out[child] < out[child + 1]) ++child;
-        if (out[root] >= out[child]) return;
-        const uint16_t t = out[root]; out[root] = out[child]; out[child] = t;
+        if (child + 1 < lim && work[child] < work[child + 1]) ++child;
+        if (work[root] >= work[child]) return;
+        const uint16_t t = work[root]; work[root] = work[child]; work[child] = t;
         root = child;
       }
     };
     for (uint64_t i = m / 2; i-- > 0;) sift(i, m);
     for (uint64_t lim = m; lim-- > 1;) {
-      const uint16_t t = out[0]; out[0] = out[lim]; out[lim] = t;
+      const uint16_t t = work[0]; work[0] = work[lim]; work[lim] = t;
       sift(0, lim);
     }
   }
   // drop duplicates (tokeniser.c:96-107), sum bucket sizes (storage.c:498-502)
   uint32_t d = 0;
   uint64_t nb = 0;
+  uint16_t last = 0;
   for (uint64_t k = 0; k < m; ++k) {
-    const uint16_t v = out[k];
-    if (d == 0 || out[d - 1] != v) { out[d++] = v; nb += code_total[v]; }
+    const uint16_t v = work[k];
+    if (d == 0 || last != v) { out[d++] = v; last = v; nb += code_total[v]; }
   }
   q_ntri[q] = d;
   q_start[q] = start_win[len < 255 ? len : 255];   // where references as long as the needle live
