@@ -289,7 +289,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
         a.pool_cap = find_pool_cap(a.keep);
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_find(a, false, uint32_t(std::min<size_t>(n, size_t(m->n_cus))), stream) < 0) return -1;
+        if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
     }
     // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
@@ -305,7 +305,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       if (maybe_mid) {                               // 65..127: the tokeniser's mid list
         a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_find(a, false, uint32_t(std::min<size_t>(n, size_t(m->n_cus))), stream) < 0) return -1;
+        if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
     }
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass

@@ -771,6 +771,58 @@ __global__ __launch_bounds__(NT) void merge_parts_kernel(const FindArgs A) {
   if (tid == 0) A.counts[q] = nres;
 }
 
+// Small limits (<= 64 rows, <= 256 ranges): the per-range lists are already sorted, so one wave
+// merges them by repeated minimum extraction -- every lane watches the heads of up to four
+// lists, a wave-wide minimum picks the winner, the winning lane advances -- instead of sorting
+// all ranges x keep keys (1 290 keys for a single needle at Geonames scale).
+__global__ __launch_bounds__(64) void merge_parts_small_kernel(const FindArgs A) {
+  __shared__ unsigned long long s_win[64];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t item = blockIdx.x, R = A.ranges, keep = A.keep;
+  const uint32_t q = A.work_list ? A.work_list[item] : item;
+  const uint32_t s0 = item * R + lane, s1 = s0 + 64, s2 = s0 + 128, s3 = s0 + 192;
+  const uint32_t n0 = lane < R ? A.part_count[s0] : 0u, n1 = lane + 64 < R ? A.part_count[s1] : 0u;
+  const uint32_t n2 = lane + 128 < R ? A.part_count[s2] : 0u, n3 = lane + 192 < R ? A.part_count[s3] : 0u;
+  uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  auto head = [&](uint32_t slot, uint32_t p, uint32_t n) {
+    return p < n ? A.part_keys[size_t(slot) * keep + p] : kKeyInf;
+  };
+  unsigned long long h0 = head(s0, 0, n0), h1 = head(s1, 0, n1), h2 = head(s2, 0, n2), h3 = head(s3, 0, n3);
+  uint32_t nres = 0;
+  for (uint32_t k = 0; k < keep; ++k) {
+    const unsigned long long mine = min(min(h0, h1), min(h2, h3));
+    unsigned long long best = mine;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+      const uint32_t lo = __shfl_xor(uint32_t(best), d), hi = __shfl_xor(uint32_t(best >> 32), d);
+      const unsigned long long other = (static_cast<unsigned long long>(hi) << 32) | lo;
+      best = min(best, other);
+    }
+    if (best == kKeyInf) break;
+    if (mine == best) {                      // keys are distinct (distinct ranks): exactly one lane, one list
+      if (h0 == best)      h0 = head(s0, ++p0, n0);
+      else if (h1 == best) h1 = head(s1, ++p1, n1);
+      else if (h2 == best) h2 = head(s2, ++p2, n2);
+      else                 h3 = head(s3, ++p3, n3);
+    }
+    if (lane == 0) s_win[k] = best;
+    ++nres;
+  }
+  __syncthreads();
+  const uint32_t T = A.q_ntri[q];
+  trigram_match_t* out = A.results + size_t(q) * A.limit;
+  if (lane < nres) {
+    const unsigned long long key = s_win[lane];
+    const uint32_t rk = uint32_t(key);
+    trigram_match_t row;
+    row.reference = A.ref_of_rank[rk];
+    row.matches = T - uint32_t(key >> 32);
+    row.weight = A.weight_of_rank[rk];
+    out[lane] = row;
+  }
+  if (lane == 0) A.counts[q] = nres;
+}
+
 // ---- base + delta: merge two per-needle result lists in result order ----------------------
 // (matches descending, weight ascending, reference ascending; the two images hold disjoint
 // references, so the first `limit` rows of the merge are the answer).  One lane per needle.
@@ -1082,6 +1134,11 @@ static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
 
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) {
   if (n_items == 0) return 0;
+  if (a.keep <= 64 && a.ranges <= 256) {
+    hipLaunchKernelGGL(merge_parts_small_kernel, dim3(n_items), dim3(64), 0, stream, a);
+    BLURRILY_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   constexpr int NT = 1024;                                    // keep <= 1024 keys per range
   const size_t lds = size_t(a.pool_cap) * 8 + sizeof(Control) + 16;
   static bool attr_done = false;
