@@ -161,19 +161,6 @@ int log_delete(trigram_map m, uint32_t ref) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for small host-buffer batches
 
-// BLURRILY_FIND_MODE=block opts into the experimental block sweep (find_block_kernel: a
-// workgroup sweeps a block of needles window-major).  Measured on MI355X it matches the
-// default one-needle-per-workgroup sweep (755 k vs 747 k needles/s): the
-// step is bound by LDS atomics and scan, not by global loads, so it is not the default.
-bool use_block_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = std::getenv("BLURRILY_FIND_MODE");
-    mode = (e && std::strcmp(e, "block") == 0) ? 1 : 0;
-  }
-  return mode == 1;
-}
-
 // Enqueue tokenise + find for n device-resident needles.
 int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_total, const uint32_t* d_tomb,
                 const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n, uint16_t limit,
@@ -239,31 +226,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   if (limit == 0) {
     BLURRILY_HIP_TRY(hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), stream));
   } else {
-    // Block mode: small limits sweep blocks of needles window-major (L2 reuse); it owns the
-    // needles with <= 64 distinct trigrams, the 65..127 ones follow through find_kernel.
-    uint32_t mini_cap = 0;
-    uint32_t block = use_block_mode() ? find_block_size(limit, &mini_cap) : 0;
-    if (block) {
-      // at least ~4 blocks per resident workgroup so the tail stays short on small batches
-      const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
-      while (block > 1 && (n + block - 1) / block < wgs * 4) block = (block + 1) / 2;
-      a.work_list = nullptr; a.n_work_dev = nullptr;
-      a.block_size = block; a.n_needles = uint32_t(n); a.n_work = uint32_t((n + block - 1) / block);
-      a.pass_base = 0; a.keep = limit; a.pool_cap = mini_cap;
-      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-      if (launch_find_block(a, uint32_t(std::min<size_t>(a.n_work, wgs)), stream) < 0) return -1;
-      if (maybe_mid) {
-        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
-        a.pool_cap = find_pool_cap(a.keep);
-        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_find(a, false, uint32_t(std::min<size_t>(n, size_t(m->n_cus))), stream) < 0) return -1;
-      }
-    }
     // Latency mode: a batch too small to fill the GPU cuts every needle's windows into ranges
     // swept by different workgroups, then merges the per-range candidates (single pass only).
     const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
     uint32_t ranges = 1;
-    if (!block && limit <= 1024 && n < wgs / 2 && ix.n_windows > 1) {
+    if (limit <= 1024 && n < wgs / 2 && ix.n_windows > 1) {
       ranges = uint32_t(std::min<size_t>(ix.n_windows, (2 * wgs) / n));
       ranges = std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit));     // merge pool
     }
@@ -293,7 +260,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       }
     }
     // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
-    for (uint32_t base = 0; !block && ranges <= 1 && base < limit; base += 1024) {
+    for (uint32_t base = 0; ranges <= 1 && base < limit; base += 1024) {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = base; a.keep = std::min<uint32_t>(1024, limit - base);
       a.pool_cap = find_pool_cap(a.keep);

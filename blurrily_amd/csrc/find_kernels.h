@@ -52,9 +52,7 @@ struct FindArgs {
   uint32_t        limit;       // row stride
   uint32_t        keep;        // rows wanted from this pass
   uint32_t        pass_base;   // rows already delivered by earlier passes
-  uint32_t        pool_cap;    // power of two, >= 4*keep (block mode: keys per mini-pool)
-  uint32_t        block_size;  // block mode: needles per workgroup (<= 64)
-  uint32_t        n_needles;   // block mode: needles in the batch (n_work counts blocks)
+  uint32_t        pool_cap;    // power of two, >= 4*keep
   unsigned long long* floor;   // [n] last key delivered by the previous pass (multi-pass only)
   // latency mode (small batches): every needle's windows are cut into `ranges` tasks
   uint32_t        short_only;  // byte-counter launches: own only needles with <= 64 distinct trigrams
@@ -69,8 +67,6 @@ int find_threads();
 uint32_t find_wgs_per_cu();   // resident byte-counter workgroups per CU (LDS and wave limits)   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
-uint32_t find_block_size(uint32_t keep, uint32_t* mini_cap);
-int launch_find_block(const FindArgs& a, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
 // Merge, per needle, two result lists that are each in result order (base image and delta image
 // hold disjoint references) into the first `limit` rows of `out`.

@@ -138,7 +138,7 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   q_start[q] = start_win[len < 255 ? len : 255];   // where references as long as the needle live
   q_nb[q] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
   if (d > 127) big_list[atomicAdd(big_count, 1u)] = q;            // 16-bit counters
-  else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, but not block mode
+  else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, two table slots per lane
 }
 
 // ------------------------------------------------------------- find kernel ---
@@ -852,225 +852,6 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
   out_counts[q] = k;
 }
 
-// =============================================================================================
-// Block sweep: one workgroup owns a block of up to 64 needles and sweeps window-major -- for
-// each window, for each needle of the block -- so that the hot slices of a window are read
-// once from HBM and then served from L1/L2 to the other needles of the block and to the other
-// workgroups of the XCD, which move through the windows at the same pace.  Per-needle state
-// between windows is a mini-pool of candidate keys and a threshold, both in LDS; pools are
-// sorted by single waves (no workgroup barrier), asynchronously to the sweep.
-// Serves needles with <= 64 distinct trigrams and limits whose mini-pool fits (host decides);
-// everything else goes through find_kernel.
-// =============================================================================================
-
-struct BlockMeta {            // one needle of the block
-  unsigned long long thr;     // admission threshold (kKeyInf: fewer than `keep` candidates so far)
-  uint32_t count;             // keys in the mini-pool (runs past the capacity while overflowing)
-  uint32_t T;                 // distinct trigrams
-  uint32_t q;                 // needle id
-  uint32_t pad;
-};
-
-struct BlockControl {
-  uint32_t slot;
-  uint32_t overflow;
-  uint32_t n_active;
-  uint32_t pad;
-};
-
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// One wave sorts a mini-pool ascending, keeps the best `keep`, tightens the threshold.
-__device__ __forceinline__ void wave_compact(unsigned long long* pool, BlockMeta* m, uint32_t cap, uint32_t keep,
-                                             uint32_t lane) {
-  const uint32_t n = min(m->count, cap);
-  uint32_t P = 1;
-  while (P < n) P <<= 1;
-  for (uint32_t i = n + lane; i < P; i += 64) pool[i] = kKeyInf;
-  wave_sync_lds();
-  for (uint32_t size = 2; size <= P; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t i = lane; i < (P >> 1); i += 64) {
-        const uint32_t lo = 2 * i - (i & (stride - 1));
-        const uint32_t hi = lo + stride;
-        const bool asc = (lo & size) == 0;
-        const unsigned long long x = pool[lo], y = pool[hi];
-        if ((x > y) == asc) { pool[lo] = y; pool[hi] = x; }
-      }
-      wave_sync_lds();
-    }
-  }
-  if (lane == 0) {
-    m->count = min(n, keep);
-    if (n >= keep && keep > 0) m->thr = pool[keep - 1];
-  }
-  wave_sync_lds();
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT, 8) void find_block_kernel(const FindArgs A) {
-  using CT = uint8_t;
-  constexpr uint32_t kNW = NT / 64;
-  constexpr uint32_t kCntBytes = kWindowSize;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // carve: counters | mini-pools | codes | meta | control
-  uint32_t* cnt32 = reinterpret_cast<uint32_t*>(smem);
-  uint4*    cnt128 = reinterpret_cast<uint4*>(smem);
-  const uint32_t B = A.block_size, MP = A.pool_cap;
-  unsigned long long* pools = reinterpret_cast<unsigned long long*>(smem + kCntBytes);
-  uint16_t* s_codes = reinterpret_cast<uint16_t*>(pools + size_t(B) * MP);          // [B][64]
-  BlockMeta* meta = reinterpret_cast<BlockMeta*>(s_codes + size_t(B) * 64);
-  BlockControl* ctl = reinterpret_cast<BlockControl*>(meta + B);
-
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t nwin = A.n_windows;
-
-  for (uint32_t i = tid; i < kCntBytes / 16; i += NT) cnt128[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-
-  for (;;) {
-    if (tid == 0) ctl->slot = atomicAdd(A.queue, 1u);
-    __syncthreads();
-    const uint32_t slot = ctl->slot;
-    __syncthreads();
-    if (slot >= A.n_work) break;
-
-    // ---- block setup: wave 0 picks the needles this kernel owns and packs the active ones --
-    if (wid == 0) {
-      const uint32_t q = slot * B + lane;
-      const bool valid = lane < B && q < A.n_needles;
-      const uint32_t T = valid ? A.q_ntri[q] : 0u;
-      const bool own = valid && T <= 64;                 // longer needles: find_kernel launches
-      const bool act = own && A.q_nb[q] != 0;
-      if (own && !act) A.counts[q] = 0;
-      const unsigned long long mask = __ballot(act);
-      const uint32_t idx = __popcll(mask & ((1ull << lane) - 1ull));
-      if (act) { meta[idx].thr = kKeyInf; meta[idx].count = 0; meta[idx].T = T; meta[idx].q = q; }
-      if (lane == 0) { ctl->n_active = __popcll(mask); ctl->overflow = 0; }
-    }
-    __syncthreads();
-    const uint32_t Bn = ctl->n_active;
-    if (Bn == 0) continue;
-    for (uint32_t x = tid; x < Bn * 64; x += NT) {
-      const uint32_t idx = x >> 6, j = x & 63;
-      const uint32_t q = meta[idx].q;
-      s_codes[x] = j < meta[idx].T ? A.qcodes[A.offsets[q] + q + j] : uint16_t(0);
-    }
-    __syncthreads();
-
-    // ---- sweep: steps (w, qi), window-major ------------------------------------------------
-    uint32_t fw = 0, fq = 0;                           // step the next table fetch belongs to
-    uint32_t ca = 0, cb = 0, na = 0, nb = 0;           // slice tables of this step / the next step
-#define BLURRILY_FETCH_STEP(A0, B0)                                               \
-  do {                                                                            \
-    A0 = B0 = 0;                                                                  \
-    if (fw < nwin) {                                                              \
-      if (lane < meta[fq].T) {                                                    \
-        const uint32_t code_ = s_codes[fq * 64 + lane];                           \
-        const uint32_t* soff_ = A.slice_off + size_t(fw) * kNumCodes;             \
-        A0 = soff_[code_]; B0 = soff_[code_ + 1];                                 \
-      }                                                                           \
-      if (++fq == Bn) { fq = 0; ++fw; }                                           \
-    }                                                                             \
-  } while (0)
-    uint4 u0, u1, u2;
-    bool head_any = false, head_more = false;
-    uint32_t hc0, hb0, hc1, hb1, hc2, hb2, hc3, hb3;
-#define BLURRILY_LOAD_HEAD(A0, B0)                                                                    \
-  do {                                                                                                \
-    head_any = head_units<kNW, 3>(A0, B0, 0u, 0u, false, wid, lane, head_more, hc0, hb0, hc1, hb1,    \
-                                  hc2, hb2, hc3, hb3);                                                \
-    u0 = load_group(A.ent, hc0, hb0);                                                                 \
-    u1 = load_group(A.ent, hc1, hb1);                                                                 \
-    u2 = load_group(A.ent, hc2, hb2);                                                                 \
-  } while (0)
-
-    BLURRILY_FETCH_STEP(ca, cb);
-    BLURRILY_FETCH_STEP(na, nb);
-    BLURRILY_LOAD_HEAD(ca, cb);
-
-    for (uint32_t w = 0; w < nwin; ++w) {
-      const uint32_t wbase = w * kWindowRanks;
-      const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
-      for (uint32_t qi = 0; qi < Bn; ++qi) {
-        const bool any = head_any, more = head_more;
-        unsigned long long* pool = pools + size_t(qi) * MP;
-        if (any) {
-          bump8<CT>(cnt32, u0);
-          bump8<CT>(cnt32, u1);
-          bump8<CT>(cnt32, u2);
-          if (more) count_rest<CT, kNW>(A.ent, cnt32, ca, cb, 0u, 0u, false, wid, lane, 3u);
-          __syncthreads();                                      // counts visible
-        }
-        BLURRILY_LOAD_HEAD(na, nb);                             // next step's head, in flight during the scan
-        if (any) {
-          Needle nd; nd.T = meta[qi].T; nd.has_floor = false;
-          for (;;) {
-            scan_core<CT, NT>(cnt128, nd, meta[qi].thr, nullptr, A.tomb, pool, MP, &meta[qi].count,
-                              &ctl->overflow, wbase, wlen);
-            __syncthreads();                                    // counters are zero again
-            if (!ctl->overflow) {
-              // a filling pool is compacted by one wave while the others move on: the needle's
-              // state is next touched Bn steps (at least one barrier) from now
-              if (meta[qi].count > MP / 2 && wid == (qi & (kNW - 1))) wave_compact(pool, &meta[qi], MP, A.keep, lane);
-              break;
-            }
-            // The pool overflowed mid-window: keep the tightened threshold, forget this
-            // window's survivors and sweep the window again (see find_kernel).
-            if (wid == 0) {
-              wave_compact(pool, &meta[qi], MP, A.keep, lane);
-              if (lane == 0) {
-                uint32_t j = 0;
-                const uint32_t n = meta[qi].count;
-                for (uint32_t i = 0; i < n; ++i)
-                  if (uint32_t(pool[i]) < wbase) pool[j++] = pool[i];
-                meta[qi].count = j;
-                ctl->overflow = 0;
-              }
-            }
-            __syncthreads();
-            count_rest<CT, kNW>(A.ent, cnt32, ca, cb, 0u, 0u, false, wid, lane, 0u);
-            __syncthreads();
-          }
-        }
-        ca = na; cb = nb;
-        BLURRILY_FETCH_STEP(na, nb);
-      }
-    }
-#undef BLURRILY_LOAD_HEAD
-#undef BLURRILY_FETCH_STEP
-    __syncthreads();                                            // every async compaction has finished
-
-    // ---- emit: each wave finishes the needles it owns --------------------------------------
-    for (uint32_t qi = wid; qi < Bn; qi += kNW) {
-      unsigned long long* pool = pools + size_t(qi) * MP;
-      wave_compact(pool, &meta[qi], MP, A.keep, lane);
-      const uint32_t nres = meta[qi].count, q = meta[qi].q, T = meta[qi].T;
-      trigram_match_t* out = A.results + size_t(q) * A.limit;
-      for (uint32_t i = lane; i < nres; i += 64) {
-        const unsigned long long key = pool[i];
-        const uint32_t rk = uint32_t(key);
-        trigram_match_t r;
-        r.reference = A.ref_of_rank[rk];
-        r.matches = T - uint32_t(key >> 32);
-        r.weight = A.weight_of_rank[rk];
-        out[i] = r;
-      }
-      if (lane == 0) A.counts[q] = nres;
-    }
-    __syncthreads();
-  }
-}
-
-size_t find_block_lds_bytes(uint32_t block_size, uint32_t mini_cap) {
-  return size_t(kWindowSize) + size_t(block_size) * (size_t(mini_cap) * 8 + 64 * 2 + sizeof(BlockMeta)) +
-         sizeof(BlockControl) + 16;
-}
-
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
   return size_t(kWindowSize) * counter_bytes + size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + sizeof(Control) + 16;
 }
@@ -1160,33 +941,6 @@ int launch_merge_rows(const trigram_match_t* a_rows, const uint32_t* a_counts, c
                      b_counts, n, limit, out, out_counts);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
-}
-
-int launch_find_block(const FindArgs& a, uint32_t grid, hipStream_t stream) {
-  if (grid == 0) return 0;
-  constexpr int NT = 1024;
-  const size_t lds = find_block_lds_bytes(a.block_size, a.pool_cap);
-  static bool attr_done = false;
-  if (!attr_done) {
-    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_block_kernel<NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((find_block_kernel<NT>), dim3(grid), dim3(NT), lds, stream, a);
-  BLURRILY_HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// Largest block (needles per workgroup) whose state fits beside the counters with two
-// workgroups per CU (80 KiB each); 0 if the limit is too large for block mode.
-uint32_t find_block_size(uint32_t keep, uint32_t* mini_cap) {
-  uint32_t cap = 32;
-  while (cap < 3 * keep) cap <<= 1;
-  *mini_cap = cap;
-  const size_t budget = 80 * 1024 - 256;
-  uint32_t b = 64;
-  while (b > 0 && find_block_lds_bytes(b, cap) > budget) --b;
-  return b >= 8 ? b : 0;
 }
 
 int find_threads() {
