@@ -623,14 +623,19 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // throughput kernel does not carry the extra live registers.  SHORT = the launch owns only
 // needles with <= 64 distinct trigrams (one table slot per lane, which frees the registers for a
 // fourth unit in flight); 65..127 follow in a launch over the tokeniser's mid list.
+// Residency is set by LDS: two workgroups per CU with byte counters, one with 16-bit counters;
+// the second launch bound (waves per SIMD) asks the register allocator for exactly that.
 template <typename CT, int NT, bool RANGED, bool SHORT>
-__global__ __launch_bounds__(NT, 8) void find_kernel(const FindArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // carve: counters | candidate pool | slice table (long needles) | control
-  uint32_t* cnt32 = reinterpret_cast<uint32_t*>(smem);
-  uint4*    cnt128 = reinterpret_cast<uint4*>(smem);
+__global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void find_kernel(const FindArgs A) {
+  // The counters are a static array: their LDS address is a compile-time constant, so the
+  // per-posting ds_add needs no base add.  Dynamic LDS behind them: candidate pool | slice table
+  // (long needles) | control.
   constexpr uint32_t kCntBytes = kWindowSize * sizeof(CT);
-  unsigned long long* pool = reinterpret_cast<unsigned long long*>(smem + kCntBytes);
+  __shared__ __attribute__((aligned(16))) uint32_t s_counters[kCntBytes / 4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* cnt32 = s_counters;
+  uint4*    cnt128 = reinterpret_cast<uint4*>(s_counters);
+  unsigned long long* pool = reinterpret_cast<unsigned long long*>(smem);
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(pool + A.pool_cap);   // [2][kCodeChunk], long needles only
   Control*  ctl = reinterpret_cast<Control*>(s_tab + 2 * kCodeChunk);
 
@@ -852,8 +857,12 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
   out_counts[q] = k;
 }
 
+// dynamic LDS of find_kernel (the counters are static)
+size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
+  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + sizeof(Control) + 16;
+}
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
-  return size_t(kWindowSize) * counter_bytes + size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + sizeof(Control) + 16;
+  return size_t(kWindowSize) * counter_bytes + find_dynamic_lds_bytes(pool_cap);
 }
 
 }  // namespace
@@ -889,11 +898,12 @@ uint32_t find_pool_cap(uint32_t keep) {
 
 template <typename CT, int NT, bool RANGED, bool SHORT>
 static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) {
-  const size_t lds = find_lds_bytes(sizeof(CT), a.pool_cap);
+  const size_t lds = find_dynamic_lds_bytes(a.pool_cap);
   static bool attr_done = false;
   if (!attr_done) {
     BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024 - int(kWindowSize * sizeof(CT))));   // static counters
     attr_done = true;
   }
   hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT>), dim3(grid), dim3(NT), lds, stream, a);
