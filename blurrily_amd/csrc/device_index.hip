@@ -227,6 +227,14 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
           sl[u0 + lane * 8 + (h >> 1)] = tmp[i];
           h = (h + 1) & 15;
         }
+        // a live lane keeps a real rank in its first slot: the kernel tells a loaded group from
+        // an idle lane's eight sentinels by that slot alone
+        for (uint32_t l = 0; l < G; ++l) {
+          uint16_t* g = sl + u0 + l * 8;
+          if (g[0] != kPadRank) continue;
+          for (uint32_t j = 1; j < 8; ++j)
+            if (g[j] != kPadRank) { std::swap(g[0], g[j]); break; }
+        }
       }
     }
   });

@@ -177,12 +177,9 @@ __device__ __forceinline__ void bump(uint32_t* cnt32, uint32_t r) {
 
 // Count one 16-byte group: eight 16-bit in-window ranks, every one of them either a real
 // rank or the padding sentinel 0xFFFF (whose counter slot the scan ignores) -- no range
-// checks.  A lane that had nothing to load holds eight sentinels and skips the group (a
-// loaded group holds at most seven).
-__device__ __forceinline__ bool group_live(const uint4 v) {
-  const uint32_t all = v.x & v.y & v.z & v.w;
-  return (all & (all >> 16) & 0xFFFFu) != kPadRank;
-}
+// checks.  A lane that had nothing to load holds eight sentinels and skips the group; a loaded
+// group always has a real rank in its first slot (device_index.hip arranges that).
+__device__ __forceinline__ bool group_live(const uint4 v) { return (v.x & 0xFFFFu) != kPadRank; }
 
 template <typename CT>
 __device__ __forceinline__ void bump8(uint32_t* cnt32, const uint4 v) {
