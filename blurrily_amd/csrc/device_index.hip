@@ -5,8 +5,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -63,6 +65,16 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   }
   int dev = 0;
   BLURRILY_HIP_TRY(hipGetDevice(&dev));
+  // BLURRILY_BUILD_TRACE=1: wall time of every build stage on stderr
+  const bool trace = std::getenv("BLURRILY_BUILD_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "blurrily_hip: index build: %-28s %8.1f ms\n", what,
+                 std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
 
   // ---- 1. reference table: every live reference once, ascending ------------
   // Each string owns exactly one leading trigram "**c" (code 784*sym(c)), so
@@ -114,6 +126,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     }
   }
   std::vector<Entry>().swap(refs);
+  stage("reference table");
 
   // ---- 2. rank every posting, count per (window, code) ----------------------
   // Buckets are independent (a code's counts, cursors and slices are touched by one worker
@@ -174,6 +187,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     }
   });
   if (failed.load()) { errno = EPROTO; return -1; }
+  stage("rank postings");
 
   // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum
   uint64_t n_slots = 0;
@@ -238,6 +252,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
       }
     }
   });
+  stage("scatter + deal units");
   // per-window bound and per-weight start window
   std::vector<uint32_t> win_max_tri(n_win, 0), start_win(256, n_win - 1);
   {
@@ -254,6 +269,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     }
   }
   std::vector<uint32_t>().swap(rank);
+  stage("window bounds");
 
   // ---- 4. upload -------------------------------------------------------------
   DeviceIndex ix;
@@ -276,6 +292,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     errno = e;
     return -1;
   }
+  stage("upload");
   ix.h_sorted_ref.swap(sorted_ref);
   ix.h_rank_of_pos.swap(rank_of_pos);
   device_index_free(out);

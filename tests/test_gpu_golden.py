@@ -111,3 +111,27 @@ def test_full_skewed_scale_properties():
     o.put_many(hay, off)
     for nd, rows in list(zip(needles, got))[:24]:
         assert rows == o.find(nd, limit), nd
+
+
+def test_config2_words_100k_batch():
+    """configs[1]: the 235 886-word haystack and ONE batch of 100 000 needles (seed 2); every
+    needle's rows are checked for order/uniqueness, 4 000 of them row for row against the oracle."""
+    hay, off = W.words(235886, 1)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, 235887, dtype=np.uint32))
+    q, qo = W.queries(hay, off, 100_000, 2)
+    rows, counts = m.find_batch_packed(q, qo, 10)
+    assert counts.max() <= 10 and counts.min() >= 1          # every needle is an edited haystack word
+    keys_ok = True
+    r = rows.astype(np.int64)
+    for k in range(9):                                       # vectorised order check: (-matches, weight, ref) ascending
+        valid = counts > k + 1
+        a, b = r[valid, k], r[valid, k + 1]
+        lt = (a[:, 1] > b[:, 1]) | ((a[:, 1] == b[:, 1]) & ((a[:, 2] < b[:, 2]) | ((a[:, 2] == b[:, 2]) & (a[:, 0] < b[:, 0]))))
+        keys_ok &= bool(lt.all())
+    assert keys_ok
+    o = Oracle()
+    o.put_many(hay, off)
+    needles = W.unpack(q, qo)
+    for i in range(0, 100_000, 25):
+        assert rows[i, :counts[i]].tolist() == o.find(needles[i], 10), needles[i]
