@@ -41,6 +41,38 @@ const Entry* sorted_view(const Bucket& bk, std::vector<Entry>& scratch) {
   return scratch.data();
 }
 
+// Sort with a pool of host threads: equal chunks sorted independently, then merged pairwise.
+template <typename T, typename Less>
+void parallel_sort(std::vector<T>& v, unsigned n_threads, Less less, bool stable) {
+  const size_t n = v.size();
+  if (n < (1u << 16) || n_threads < 2) {
+    if (stable) std::stable_sort(v.begin(), v.end(), less); else std::sort(v.begin(), v.end(), less);
+    return;
+  }
+  unsigned parts = 1;
+  while (parts * 2 <= n_threads && parts < 64) parts *= 2;
+  std::vector<size_t> cut(parts + 1);
+  for (unsigned i = 0; i <= parts; ++i) cut[i] = n * i / parts;
+  {
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < parts; ++i)
+      pool.emplace_back([&, i]() {
+        if (stable) std::stable_sort(v.begin() + cut[i], v.begin() + cut[i + 1], less);
+        else std::sort(v.begin() + cut[i], v.begin() + cut[i + 1], less);
+      });
+    for (auto& th : pool) th.join();
+  }
+  for (unsigned width = 1; width < parts; width *= 2) {     // std::inplace_merge is stable
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i + width < parts; i += 2 * width)
+      pool.emplace_back([&, i, width]() {
+        std::inplace_merge(v.begin() + cut[i], v.begin() + cut[i + width],
+                           v.begin() + cut[std::min(parts, i + 2 * width)], less);
+      });
+    for (auto& th : pool) th.join();
+  }
+}
+
 }  // namespace
 
 void device_index_free(DeviceIndex* ix) {
@@ -76,6 +108,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     t_last = now;
   };
 
+  const unsigned n_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+
   // ---- 1. reference table: every live reference once, ascending ------------
   // Each string owns exactly one leading trigram "**c" (code 784*sym(c)), so
   // the 27 leading buckets list every reference exactly once.
@@ -89,16 +123,16 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
       const Bucket& bk = host.bucket(s * kBase * kBase);
       refs.insert(refs.end(), bk.e, bk.e + bk.used);
     }
-    std::sort(refs.begin(), refs.end(), [](const Entry& l, const Entry& r) { return l.ref < r.ref; });
+    parallel_sort(refs, n_threads, [](const Entry& l, const Entry& r) { return l.ref < r.ref; }, false);
   } else {
     refs.reserve(nnz);
     for (uint32_t t = 0; t < kNumCodes; ++t) {
       const Bucket& bk = host.bucket(t);
       refs.insert(refs.end(), bk.e, bk.e + bk.used);
     }
-    std::sort(refs.begin(), refs.end(), [](const Entry& l, const Entry& r) {
+    parallel_sort(refs, n_threads, [](const Entry& l, const Entry& r) {
       return l.ref != r.ref ? l.ref < r.ref : l.weight < r.weight;
-    });
+    }, false);
     refs.erase(std::unique(refs.begin(), refs.end(),
                            [](const Entry& l, const Entry& r) { return l.ref == r.ref && l.weight == r.weight; }),
                refs.end());
@@ -116,8 +150,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   {
     std::vector<uint32_t> order(n_refs);
     for (uint32_t i = 0; i < n_refs; ++i) { order[i] = i; sorted_ref[i] = refs[i].ref; }
-    std::stable_sort(order.begin(), order.end(),
-                     [&](uint32_t l, uint32_t r) { return refs[l].weight < refs[r].weight; });  // refs[] is ref-ascending
+    parallel_sort(order, n_threads,                                // refs[] is ref-ascending: a stable
+                  [&](uint32_t l, uint32_t r) { return refs[l].weight < refs[r].weight; }, true);   // sort by weight
     for (uint32_t rk = 0; rk < n_refs; ++rk) {
       const uint32_t pos = order[rk];
       rank_of_pos[pos] = rk;
@@ -141,7 +175,6 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     code_total[t] = host.bucket(t).used;
     bucket_base[t + 1] = bucket_base[t] + code_total[t];
   }
-  const unsigned n_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
   std::atomic<int> failed{0};
   auto parallel_codes = [&](auto&& body) {
     std::atomic<uint32_t> next{0};
