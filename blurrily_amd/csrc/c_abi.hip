@@ -207,8 +207,8 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
 #ifdef BLURRILY_PHASE_PROFILE
   {
     static unsigned long long* d_phase = nullptr;
-    if (!d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phase), 8192 * 8 * 8));
-    BLURRILY_HIP_TRY(hipMemsetAsync(d_phase, 0, 8192 * 8 * 8, stream));
+    if (!d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phase), 8192 * 16 * 8));
+    BLURRILY_HIP_TRY(hipMemsetAsync(d_phase, 0, 8192 * 16 * 8, stream));
     a.phase_clocks = d_phase;
     g_phase_clocks = d_phase;
   }
@@ -535,7 +535,7 @@ void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabl
 int blurrily_debug_phase_clocks(unsigned long long* out, size_t n_workgroups) {
   if (!g_phase_clocks) return -1;
   (void)hipDeviceSynchronize();
-  return hipMemcpy(out, g_phase_clocks, n_workgroups * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  return hipMemcpy(out, g_phase_clocks, n_workgroups * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 

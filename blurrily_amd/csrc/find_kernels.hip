@@ -48,6 +48,15 @@ namespace {
 
 constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 
+#ifndef BLURRILY_COOP
+#define BLURRILY_COOP 1                // 1: one wave per step publishes the units (sweep_coop); 0: every wave walks the table
+#endif
+#ifndef BLURRILY_COOP_ROTATE
+#define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
+#endif
+#ifndef BLURRILY_COOP_HEAD_UNITS
+#define BLURRILY_COOP_HEAD_UNITS 2     // sweep_coop: units per wave of the next window in flight during the scan
+#endif
 #ifndef BLURRILY_HEAD_UNITS
 #define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
 #endif
@@ -55,13 +64,17 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 // Optional phase profile (make profile): wave 0's shader-clock time per phase of the sweep,
 // accumulated per workgroup into FindArgs::phase_clocks[blockIdx.x * 8 + phase].
 #ifdef BLURRILY_PHASE_PROFILE
-#define PHASE_DECL unsigned long long ph_last = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_DECL unsigned long long ph_last = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_units = 0, ph_lanes = 0
+// head units of wave 0 and their live lanes (lane utilisation of the LDS atomics)
+#define PHASE_UNIT(v) do { const unsigned long long m_ = __ballot(group_live(v)); if (m_) { ++ph_units; ph_lanes += __popcll(m_); } } while (0)
 #define PHASE_MARK(i) do { const unsigned long long t_ = clock64(); ph_acc[i] += t_ - ph_last; ph_last = t_; } while (0)
 #define PHASE_FLUSH(A) do { if (threadIdx.x == 0 && (A).phase_clocks) { \
-    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(A).phase_clocks[blockIdx.x * 8 + i_], ph_acc[i_]); } } while (0)
+    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + i_], ph_acc[i_]); \
+    atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + 8], ph_units); atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + 9], ph_lanes); } } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_MARK(i)
+#define PHASE_UNIT(v)
 #define PHASE_FLUSH(A)
 #endif
 constexpr uint64_t kKeyInf    = ~0ull;
@@ -575,6 +588,8 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     PHASE_MARK(0);                                              // loop overhead
     if (any) {
       // ---- count window w: its head was loaded one window ago ---------------------------
+      PHASE_UNIT(u0); PHASE_UNIT(u1); PHASE_UNIT(u2);
+      if (KP > 3) PHASE_UNIT(u3);
       bump8<CT>(cnt32, u0);
       bump8<CT>(cnt32, u1);
       bump8<CT>(cnt32, u2);
@@ -616,6 +631,184 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 #undef BLURRILY_FETCH_TABLE
 }
 
+// ---- cooperative flavour (needles with <= 64 distinct trigrams: nearly all of them) --------
+// In sweep_pipelined every wave walks the needle's slice table itself to find its units: sixteen
+// times the same work.  Here ONE wave per step (rotating) cuts the slices of the next visited
+// window into units and publishes them as descriptors {first entry, slice end} in an LDS ring;
+// after the step's first barrier every wave just reads the descriptors of its units (unit k
+// belongs to wave k mod kNW).  The next visited window is decided one step ahead (windows that
+// cannot hold a candidate are stepped over without a barrier), so the producing wave has the
+// table in registers before it needs it.
+constexpr uint32_t kRingUnits = 256;                            // descriptors per ring slot
+struct UnitRing {
+  uint2    desc[2][kRingUnits];                                 // .x first entry of the unit, .y end of its slice
+  uint32_t n_units[2];                                          // kRingOverflow: too many units, walk the table
+};
+constexpr uint32_t kRingOverflow = 0xFFFFFFFFu;
+
+template <typename CT, int NT, int KP>
+__device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
+                           unsigned long long* pool, Control* ctl, UnitRing* ring, const uint32_t w0,
+                           const uint32_t w1, const uint32_t ws) {
+  constexpr uint32_t kNW = NT / 64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t tc = nd.T;                                     // <= 64
+  const bool own = lane < tc;
+  const uint32_t code = own ? codes[lane] : 0u;
+  const uint32_t n_visit = w1 - w0;
+#define BLURRILY_WIN_AT(i_) ((i_) < n_visit ? (ws + (i_) < w1 ? ws + (i_) : ws + (i_) - n_visit) : w1)
+#define BLURRILY_WMT_AT(i_) A.win_max_tri[min(BLURRILY_WIN_AT(i_), w1 - 1)]
+  // first visit index >= from_ whose window can hold a candidate (n_visit: none)
+#define BLURRILY_NEXT_VISIT(from_, out_)                                         \
+  do {                                                                           \
+    out_ = (from_);                                                              \
+    while (out_ < n_visit && min(tc, BLURRILY_WMT_AT(out_)) <                    \
+           matches_needed(ctl->thr, tc, BLURRILY_WIN_AT(out_) * kWindowRanks)) ++out_; \
+  } while (0)
+#define BLURRILY_FETCH_TABLE(w_, A0, B0)                                         \
+  do {                                                                           \
+    A0 = B0 = 0;                                                                 \
+    if ((w_) < w1 && own) {                                                      \
+      const uint32_t idx_ = (w_) * kNumCodes + code;                             \
+      A0 = A.slice_off[idx_]; B0 = A.slice_off[idx_ + 1];                        \
+    }                                                                            \
+  } while (0)
+  // this wave publishes the units of the table (ta, tb) into ring slot s_
+#define BLURRILY_PRODUCE(s_, ta, tb)                                             \
+  do {                                                                           \
+    const uint32_t units_ = slice_units(ta, tb);                                 \
+    uint32_t incl_ = units_;                                                     \
+    _Pragma("unroll") for (uint32_t d_ = 1; d_ < 64; d_ <<= 1) {                 \
+      const uint32_t up_ = __shfl_up(incl_, d_);                                 \
+      if (lane >= d_) incl_ += up_;                                              \
+    }                                                                            \
+    const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
+    if (total_ > kRingUnits) {                                                   \
+      if (lane == 0) ring->n_units[s_] = kRingOverflow;                          \
+    } else {                                                                     \
+      uint32_t at_ = incl_ - units_;                                             \
+      for (uint32_t j_ = 0; j_ < units_; ++j_, ++at_)                            \
+        ring->desc[s_][at_] = make_uint2(ta + j_ * 512, tb);                     \
+      if (lane == 0) ring->n_units[s_] = total_;                                 \
+    }                                                                            \
+  } while (0)
+  // heads of this wave for ring slot s_: units wid, wid+kNW, ... (at most KP)
+#define BLURRILY_LOAD_HEADS(s_, n_)                                              \
+  do {                                                                           \
+    u0 = u1 = u2 = u3 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);      \
+    if ((n_) != kRingOverflow) {                                                 \
+      if (wid < (n_))           { const uint2 d_ = ring->desc[s_][wid];           u0 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
+      if (KP > 1 && wid + kNW < (n_))     { const uint2 d_ = ring->desc[s_][wid + kNW];     u1 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
+      if (KP > 2 && wid + 2 * kNW < (n_)) { const uint2 d_ = ring->desc[s_][wid + 2 * kNW]; u2 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
+      if (KP > 3 && wid + 3 * kNW < (n_)) { const uint2 d_ = ring->desc[s_][wid + 3 * kNW]; u3 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
+    }                                                                            \
+  } while (0)
+  // units of ring slot s_ from the first_-th unit of this wave on, loaded and counted in place
+#define BLURRILY_COUNT_FROM(s_, n_, first_)                                      \
+  do {                                                                           \
+    uint4 pend_ = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);            \
+    for (uint32_t k_ = wid + (first_) * kNW; k_ < (n_); k_ += kNW) {             \
+      const uint2 d_ = ring->desc[s_][k_];                                       \
+      const uint4 v_ = load_group(A.ent, d_.x + lane * 8, d_.y);                 \
+      bump8<CT>(cnt32, pend_);                                                   \
+      pend_ = v_;                                                                \
+    }                                                                            \
+    bump8<CT>(cnt32, pend_);                                                     \
+  } while (0)
+
+  uint4 u0, u1, u2, u3;
+  uint32_t ta = 0, tb = 0;                                      // table this wave will publish next
+  PHASE_DECL;
+  uint32_t i_cur = 0, i_next, i_next2;
+#if BLURRILY_COOP_ROTATE
+#define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
+#else
+#define BLURRILY_PRODUCER(e_) (kNW - 1)                        /* units go round robin: the last wave has the fewest */
+#endif
+  // prologue: the producer publishes the first window, everyone agrees on the second
+  if (wid == BLURRILY_PRODUCER(0u)) {
+    BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(0u), ta, tb);
+    BLURRILY_PRODUCE(0u, ta, tb);
+  }
+  __syncthreads();
+  BLURRILY_NEXT_VISIT(1u, i_next);
+  if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(i_next), ta, tb);
+  {
+    const uint32_t n0 = ring->n_units[0];
+    BLURRILY_LOAD_HEADS(0u, n0);
+  }
+
+  for (uint32_t e = 0; i_cur < n_visit; ++e) {
+    const uint32_t s = e & 1;
+    const uint32_t w = BLURRILY_WIN_AT(i_cur);
+    const uint32_t wbase = w * kWindowRanks;
+    const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+    const uint32_t n_units = ring->n_units[s];
+    PHASE_MARK(0);                                              // loop overhead
+    // ---- count window w ------------------------------------------------------------------
+    if (n_units == kRingOverflow) {                             // too many units for the ring: walk the table
+      uint32_t fa, fb;
+      BLURRILY_FETCH_TABLE(w, fa, fb);
+      count_rest<CT, kNW>(A.ent, cnt32, fa, fb, 0u, 0u, false, wid, lane, 0u);
+    } else if (n_units) {
+      PHASE_UNIT(u0);
+      if (KP > 1) PHASE_UNIT(u1);
+      if (KP > 2) PHASE_UNIT(u2);
+      if (KP > 3) PHASE_UNIT(u3);
+      bump8<CT>(cnt32, u0);
+      if (KP > 1) bump8<CT>(cnt32, u1);
+      if (KP > 2) bump8<CT>(cnt32, u2);
+      if (KP > 3) bump8<CT>(cnt32, u3);
+      PHASE_MARK(1);                                            // head counted
+      if (n_units > wid + KP * kNW) BLURRILY_COUNT_FROM(s, n_units, uint32_t(KP));
+    }
+    PHASE_MARK(2);                                              // rest counted
+    // the producer publishes the next visited window (its table arrived a step ago)
+    if (wid == BLURRILY_PRODUCER(e + 1)) {
+      if (i_next < n_visit) BLURRILY_PRODUCE(s ^ 1u, ta, tb);
+      else if (lane == 0) ring->n_units[s ^ 1u] = 0;
+    }
+    PHASE_MARK(7);                                              // (producer turn) next window's units published
+    __syncthreads();                                            // counts and next descriptors visible
+    PHASE_MARK(3);                                              // barrier after count
+    // ---- next window's heads in flight during the scan; decide the window after it --------
+    const uint32_t n_next = ring->n_units[s ^ 1u];
+    BLURRILY_LOAD_HEADS(s ^ 1u, n_next);
+    BLURRILY_NEXT_VISIT(i_next + 1, i_next2);                   // uniform: thr only changes behind select's barriers
+    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(i_next2), ta, tb);
+    PHASE_MARK(4);                                              // next heads issued, window after chosen
+    if (n_units) {
+      for (;;) {
+        scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
+        PHASE_MARK(5);                                          // scan
+        __syncthreads();                                        // counters are zero again
+        PHASE_MARK(6);                                          // barrier after scan
+        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
+        if (n_units == kRingOverflow) {                         // pool overflow: sweep window w again
+          uint32_t fa, fb;
+          BLURRILY_FETCH_TABLE(w, fa, fb);
+          count_rest<CT, kNW>(A.ent, cnt32, fa, fb, 0u, 0u, false, wid, lane, 0u);
+        } else {
+          BLURRILY_COUNT_FROM(s, n_units, 0u);
+        }
+        __syncthreads();
+      }
+    }
+    i_cur = i_next;
+    i_next = i_next2;
+  }
+  PHASE_FLUSH(A);
+  __syncthreads();                                              // ring and ctl quiet before the needle ends
+#undef BLURRILY_PRODUCER
+#undef BLURRILY_COUNT_FROM
+#undef BLURRILY_LOAD_HEADS
+#undef BLURRILY_PRODUCE
+#undef BLURRILY_FETCH_TABLE
+#undef BLURRILY_NEXT_VISIT
+#undef BLURRILY_WMT_AT
+#undef BLURRILY_WIN_AT
+}
+
 // RANGED = latency mode (a needle's windows cut into ranges); a separate instantiation so the
 // throughput kernel does not carry the extra live registers.  SHORT = the launch owns only
 // needles with <= 64 distinct trigrams (one table slot per lane, which frees the registers for a
@@ -635,6 +828,8 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
   unsigned long long* pool = reinterpret_cast<unsigned long long*>(smem);
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(pool + A.pool_cap);   // [2][kCodeChunk], long needles only
   Control*  ctl = reinterpret_cast<Control*>(s_tab + 2 * kCodeChunk);
+  UnitRing* ring = reinterpret_cast<UnitRing*>(reinterpret_cast<unsigned char*>(ctl) + 64);
+  (void)ring;
 
   const uint32_t tid = threadIdx.x;
 
@@ -686,7 +881,9 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
-    if constexpr (SHORT) {                                                                              \
+    if constexpr (SHORT && !RANGED && BLURRILY_COOP) {                                                            \
+      sweep_coop<CT, NT, BLURRILY_COOP_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_);    \
+    } else if constexpr (SHORT) {                                                                       \
       sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
       sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_);                 \
@@ -856,7 +1053,8 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
 
 // dynamic LDS of find_kernel (the counters are static)
 size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
-  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + sizeof(Control) + 16;
+  static_assert(sizeof(Control) <= 64, "the unit ring sits 64 bytes behind the control block");
+  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 16;
 }
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
   return size_t(kWindowSize) * counter_bytes + find_dynamic_lds_bytes(pool_cap);

@@ -271,3 +271,25 @@ def test_window_boundaries_and_cross_window_ties(n):
     m.put("paris", n + 10, 0); o.put(b"paris", n + 10, 0)          # lives alone at the end of the ranks
     for limit in (1, 10, 1024, 1025, 65535):
         _check_batch(m, o, [b"london", b"londno", b"paris", b"pa"], limit)
+
+
+def test_dense_and_empty_windows_mixed():
+    """Windows whose slices hold more units than the kernel's unit ring (one string repeated
+    70 000 times) next to ordinary windows and windows with nothing for the needle: the
+    ring-overflow walk, the ring path and the skipped steps in one sweep."""
+    hay, off = W.words(150000, seed=21)
+    n = len(off) - 1
+    m, o = RawMap(), Oracle()
+    refs = np.arange(1, n + 1, dtype=np.uint32)
+    m.put_many_packed(hay, off, refs)
+    o.put_many(hay, off, refs)
+    rep = 70000
+    packed = np.frombuffer(b"london" * rep, dtype=np.uint8)
+    roff = np.arange(rep + 1, dtype=np.uint64) * 6
+    rrefs = np.arange(n + 1, n + rep + 1, dtype=np.uint32)
+    m.put_many_packed(packed, roff, rrefs)
+    o.put_many(packed, roff, rrefs)
+    m.put("zzzzqqqqzzzzqqqqzzzzqqqq", 10**6, 0); o.put(b"zzzzqqqqzzzzqqqqzzzzqqqq", 10**6, 0)
+    needles = [b"london", b"londno", b"lon", b"zzzzqqqq", b"zq", b"don"] + W.unpack(hay, off)[:200]
+    for limit in (1, 10, 300):
+        _check_batch(m, o, needles, limit)

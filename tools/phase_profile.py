@@ -16,8 +16,10 @@ import numpy as np  # noqa: E402
 import workloads as W  # noqa: E402
 from blurrily_amd import RawMap, _native  # noqa: E402
 
-PHASES = ["loop/table", "count prefetched", "count rest", "barrier(count)", "issue next head", "scan",
-          "barrier(scan)", "select"]
+# needles with <= 64 trigrams run sweep_coop: there slot 0 also holds the selection of the previous step and
+# slot 7 is the publishing turn (next window's unit descriptors); in sweep_pipelined slot 7 is the selection
+PHASES = ["loop/table (+select)", "count prefetched", "count rest", "barrier(count)", "issue next head", "scan",
+          "barrier(scan)", "publish | select"]
 
 
 def main():
@@ -31,20 +33,24 @@ def main():
     info = m.device_info()
     lib = _native.lib()
     lib.blurrily_debug_phase_clocks.argtypes = [C.c_void_p, C.c_size_t]
-    for batch in (1, nq):
+    for batch in (512, nq):
         qp, qo = W.queries(hay, off, batch, 3000)
         t = time.perf_counter()
         rows, counts = m.find_batch_packed(qp, qo, 10)
         dt = time.perf_counter() - t
         nwg = min(batch, 512)
-        buf = np.zeros((nwg, 8), dtype=np.uint64)
+        buf = np.zeros((nwg, 16), dtype=np.uint64)
         assert lib.blurrily_debug_phase_clocks(buf.ctypes.data, nwg) == 0
-        tot = buf.sum(axis=0).astype(np.float64)
+        tot_all = buf.sum(axis=0).astype(np.float64)
+        tot = tot_all[:8]
         per_window = tot / (batch * info["n_windows"])
         print(f"batch {batch}: {dt * 1e3:.2f} ms wall, {info['n_windows']} windows; clocks per (query, window):")
         for name, v in zip(PHASES, per_window):
-            print(f"   {name:18s} {v:9.0f}")
-        print(f"   {'TOTAL':18s} {per_window.sum():9.0f}")
+            print(f"   {name:22s} {v:9.0f}")
+        print(f"   {'TOTAL':22s} {per_window.sum():9.0f}")
+        if tot_all[8]:
+            print(f"   wave 0 head units per (query, window): {tot_all[8] / (batch * info['n_windows']):.2f}, "
+                  f"live lanes per unit: {tot_all[9] / tot_all[8]:.1f} of 64")
 
 
 if __name__ == "__main__":
