@@ -41,6 +41,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace blurrily {
 
@@ -50,6 +51,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 
 #ifndef BLURRILY_COOP
 #define BLURRILY_COOP 1                // 1: one wave per step publishes the units (sweep_coop); 0: every wave walks the table
+#endif
+#ifndef BLURRILY_NIBBLE
+#define BLURRILY_NIBBLE 1              // needles with <= 15 trigrams count in 4 bits, two windows per step
 #endif
 #ifndef BLURRILY_COOP_ROTATE
 #define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
@@ -169,6 +173,68 @@ template <> struct Packing<uint16_t> {
                             kTop = 0x8000u, kMask = 0xFFFFu;
 };
 
+// 4-bit counters for needles with at most 15 distinct trigrams (two needles in three at
+// Geonames scale): the same 64 KiB of LDS then hold TWO windows, so a sweep takes half the steps.
+// Counter index = (window parity << 16) | in-window rank; the two padding slots (0xFFFF of either
+// half) are the top nibble of their word, so their overflow leaves the word.
+struct Nib {};
+template <> struct Packing<Nib> {
+  static constexpr uint32_t kPerWord = 8, kBits = 4, kMask = 0xFu;
+};
+
+// What the scan needs to know about a packing: which vectors to read, which counters reached
+// `need` (one bit per counter, at the top bit of its field), where the padding slots are.
+template <typename CT> struct ScanTraits {
+  using P = Packing<CT>;
+  static constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
+  struct Need { uint32_t bias; };
+  static __device__ __forceinline__ Need prepare(uint32_t need) { return Need{(P::kTop - need) * P::kOnes}; }
+  static __device__ __forceinline__ uint32_t hits(uint32_t v, Need n) { return (v + n.bias) & P::kHi; }
+  static __device__ __forceinline__ uint32_t any_hit(uint4 v, Need n) {
+    return ((v.x + n.bias) | (v.y + n.bias) | (v.z + n.bias) | (v.w + n.bias)) & P::kHi;
+  }
+  static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) { return (wlen * uint32_t(sizeof(CT)) + 15) / 16; }
+  static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t i) {
+    if (i == kVecs - 1) v.w &= ~(P::kMask << (32 - P::kBits));    // slot 0xFFFF counts padding
+    return v;
+  }
+  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) { return wbase + idx; }
+  // a short window does not reach the vector holding the padding slot: clear it here
+  static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
+    if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+  }
+};
+template <> struct ScanTraits<Nib> {
+  using P = Packing<Nib>;
+  static constexpr uint32_t kVecs = kWindowSize / 16;               // the same 64 KiB
+  // counter >= need, with c = counter, lo = c & 7:  need <= 8: c >= 8 or lo + (8 - need) >= 8;
+  //                                                 need >  8: c >= 8 and lo + (16 - need) >= 8
+  struct Need { uint32_t bias; bool low; };
+  static __device__ __forceinline__ Need prepare(uint32_t need) {
+    return need <= 8 ? Need{(8 - need) * 0x11111111u, true} : Need{(16 - need) * 0x11111111u, false};
+  }
+  static __device__ __forceinline__ uint32_t hits(uint32_t v, Need n) {
+    const uint32_t t = (v & 0x77777777u) + n.bias;
+    return (n.low ? (t | v) : (t & v)) & 0x88888888u;
+  }
+  static __device__ __forceinline__ uint32_t any_hit(uint4 v, Need n) {
+    return hits(v.x, n) | hits(v.y, n) | hits(v.z, n) | hits(v.w, n);
+  }
+  // counter indices in use: [0, wlen) for one window, [0, 65536 + wlen - 65535) for two
+  static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) {
+    return ((wlen <= kWindowRanks ? wlen : wlen + 1) + 31) / 32;
+  }
+  static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t i) {
+    if ((i & (kVecs / 2 - 1)) == kVecs / 2 - 1) v.w &= 0x0FFFFFFFu;   // slots 0xFFFF and 0x1FFFF count padding
+    return v;
+  }
+  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) { return wbase + idx - (idx >> 16); }
+  static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
+    if (nv < kVecs / 2 && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 2 - 1] = 0;
+    if (nv < kVecs && tid == 1) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+  }
+};
+
 // A candidate is one 64-bit key: (T - matches) in the high word, rank in the low word.  Ranks
 // follow (weight, reference), so ascending keys are the reference's result order.
 struct Control {            // workgroup-shared scalars
@@ -201,6 +267,32 @@ __device__ __forceinline__ void bump8(uint32_t* cnt32, const uint4 v) {
   bump<CT>(cnt32, v.y & 0xFFFFu); bump<CT>(cnt32, v.y >> 16);
   bump<CT>(cnt32, v.z & 0xFFFFu); bump<CT>(cnt32, v.z >> 16);
   bump<CT>(cnt32, v.w & 0xFFFFu); bump<CT>(cnt32, v.w >> 16);
+}
+
+// 4-bit flavour: HALF = parity of the unit's window (compile-time, so it lands in the ds_add's
+// immediate offset)
+template <uint32_t HALF>
+__device__ __forceinline__ void bump_nib(uint32_t* cnt32, uint32_t r) {
+  __hip_atomic_fetch_add(&cnt32[HALF * (kWindowSize / 8) + (r >> 3)], 1u << ((r & 7u) * 4),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <uint32_t HALF>
+__device__ __forceinline__ void bump8_nib(uint32_t* cnt32, const uint4 v) {
+  if (!group_live(v)) return;
+  bump_nib<HALF>(cnt32, v.x & 0xFFFFu); bump_nib<HALF>(cnt32, v.x >> 16);
+  bump_nib<HALF>(cnt32, v.y & 0xFFFFu); bump_nib<HALF>(cnt32, v.y >> 16);
+  bump_nib<HALF>(cnt32, v.z & 0xFFFFu); bump_nib<HALF>(cnt32, v.z >> 16);
+  bump_nib<HALF>(cnt32, v.w & 0xFFFFu); bump_nib<HALF>(cnt32, v.w >> 16);
+}
+// count one unit; `half` (uniform) = parity of its window, used by the 4-bit flavour only
+template <typename CT>
+__device__ __forceinline__ void bump_unit(uint32_t* cnt32, const uint4 v, uint32_t half) {
+  if constexpr (std::is_same<CT, Nib>::value) {
+    if (half) bump8_nib<1>(cnt32, v); else bump8_nib<0>(cnt32, v);
+  } else {
+    (void)half;
+    bump8<CT>(cnt32, v);
+  }
 }
 
 __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uint32_t b) {
@@ -262,22 +354,22 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
                                           uint32_t* overflow, uint32_t wbase, uint32_t wlen,
                                           const uint32_t need_floor = 0) {
   using P = Packing<CT>;
-  constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
+  using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x;
   const uint32_t need = max(matches_needed(thr, nd.T, wbase), need_floor);
-  const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
+  const uint32_t nvec = S::nvec(wlen);
   if (need <= nd.T) {
-    const uint32_t bias = (P::kTop - need) * P::kOnes;
+    const typename S::Need nq = S::prepare(need);
     // slow path of one vector: some counter reached `need`
     auto harvest = [&](const uint4 v, const uint32_t i) {
       auto word = [&](const uint32_t wv, const uint32_t j) {
-        uint32_t m = (wv + bias) & P::kHi;
+        uint32_t m = S::hits(wv, nq);
         while (m) {
           const uint32_t bit = __ffs(m) - 1;
           m &= m - 1;
           const uint32_t pos = bit / P::kBits;
           const uint32_t cnt = (wv >> (pos * P::kBits)) & P::kMask;
-          const uint32_t rank = wbase + (i * 4 + j) * P::kPerWord + pos;
+          const uint32_t rank = S::rank_of(wbase, (i * 4 + j) * P::kPerWord + pos);
           const unsigned long long key = (static_cast<unsigned long long>(nd.T - cnt) << 32) | rank;
           bool pass = key <= thr;
           if (nd.has_floor) pass = pass && key > *floor;
@@ -291,20 +383,16 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       };
       word(v.x, 0); word(v.y, 1); word(v.z, 2); word(v.w, 3);
     };
-    // one SWAR test per vector: the top bit of a lane is set iff its counter >= need
-    auto test = [&](uint4 v, const uint32_t i) {
-      if (i == kVecs - 1) v.w &= ~(P::kMask << (32 - P::kBits));      // slot 0xFFFF counts padding
-      const uint32_t hit = ((v.x + bias) | (v.y + bias) | (v.z + bias) | (v.w + bias)) & P::kHi;
-      if (hit) harvest(v, i);
-    };
     for (uint32_t i = tid; i < nvec; i += NT) {
-      const uint4 v = cnt128[i];
+      uint4 v = cnt128[i];
       // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held
       // in four VGPRs for the whole sweep and spilled to scratch under the 64-VGPR budget.
       uint32_t z = 0;
       asm volatile("" : "+v"(z));
       cnt128[i] = make_uint4(z, z, z, z);
-      test(v, i);
+      v = S::mask_pad(v, i);
+      // one SWAR test per vector: the top bit of a field is set iff its counter >= need
+      if (S::any_hit(v, nq)) harvest(v, i);
     }
   } else {
     // nothing in this window can enter the pool any more: just clear the counters
@@ -314,8 +402,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       cnt128[i] = make_uint4(z, z, z, z);
     }
   }
-  // a short window does not reach the vector holding the padding slot: clear it here
-  if (nvec < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+  S::clear_unreached_pad(cnt128, nvec, tid);
 }
 
 // Cold start: with no threshold yet, every non-zero counter of a window would flood the pool
@@ -326,22 +413,20 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
 template <typename CT, int NT>
 __device__ __forceinline__ uint32_t cold_start_need(const uint4* cnt128, uint32_t T, uint32_t keep, Control* ctl,
                                                     uint32_t wlen) {
-  using P = Packing<CT>;
-  constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
+  using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const uint32_t nvec = (wlen * sizeof(CT) + 15) / 16;
+  const uint32_t nvec = S::nvec(wlen);
   uint32_t lo = 1, hi = T;                               // answer in [lo, hi]; lo = 1 means "no restriction"
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (tid == 0) ctl->tally = 0;
     __syncthreads();
-    const uint32_t bias = (P::kTop - mid) * P::kOnes;
+    const typename S::Need nq = S::prepare(mid);
     uint32_t mine = 0;
     for (uint32_t i = tid; i < nvec; i += NT) {
-      uint4 v = cnt128[i];
-      if (i == kVecs - 1) v.w &= ~(P::kMask << (32 - P::kBits));    // slot 0xFFFF counts padding
-      mine += __popc((v.x + bias) & P::kHi) + __popc((v.y + bias) & P::kHi) +
-              __popc((v.z + bias) & P::kHi) + __popc((v.w + bias) & P::kHi);
+      const uint4 v = S::mask_pad(cnt128[i], i);
+      mine += __popc(S::hits(v.x, nq)) + __popc(S::hits(v.y, nq)) + __popc(S::hits(v.z, nq)) +
+              __popc(S::hits(v.w, nq));
     }
 #pragma unroll
     for (uint32_t d = 32; d; d >>= 1) mine += __shfl_xor(mine, int(d));
@@ -650,26 +735,45 @@ template <typename CT, int NT, int KP>
 __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
                            unsigned long long* pool, Control* ctl, UnitRing* ring, const uint32_t w0,
                            const uint32_t w1, const uint32_t ws) {
+  // A step covers kWPS windows: one with byte counters, two with 4-bit counters (CT = Nib,
+  // needles with <= 15 trigrams; lane l of the table then holds trigram l & 15 of window
+  // 2 * step + (l >> 4), and a unit's descriptor carries that parity in bit 0).
+  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  constexpr uint32_t kWPS = kNib ? 2 : 1;
   constexpr uint32_t kNW = NT / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t tc = nd.T;                                     // <= 64
-  const bool own = lane < tc;
-  const uint32_t code = own ? codes[lane] : 0u;
-  const uint32_t n_visit = w1 - w0;
-#define BLURRILY_WIN_AT(i_) ((i_) < n_visit ? (ws + (i_) < w1 ? ws + (i_) : ws + (i_) - n_visit) : w1)
-#define BLURRILY_WMT_AT(i_) A.win_max_tri[min(BLURRILY_WIN_AT(i_), w1 - 1)]
-  // first visit index >= from_ whose window can hold a candidate (n_visit: none)
+  const uint32_t tc = nd.T;                                     // <= 64 (<= 15 with 4-bit counters)
+  const uint32_t my_tri = kNib ? (lane & 15u) : lane;           // the slice this lane holds in the table ...
+  const uint32_t my_half = kNib ? (lane >> 4) : 0u;             // ... and the window of the step it belongs to
+  const bool own = my_tri < tc && my_half < kWPS;
+  const uint32_t code = own ? codes[my_tri] : 0u;
+  const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
+  const uint32_t n_visit = v1 - v0;
+#define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
+  // most trigrams of the needle a reference of the step's window(s) can hold
+#define BLURRILY_WMT_AT(i_, out_)                                                \
+  do {                                                                           \
+    const uint32_t p_ = min(BLURRILY_STEP_AT(i_), v1 - 1) * kWPS;                \
+    out_ = A.win_max_tri[p_];                                                    \
+    if (kNib && p_ + 1 < w1) out_ = max(out_, A.win_max_tri[p_ + 1]);            \
+  } while (0)
+  // first visit index >= from_ whose step can hold a candidate (n_visit: none)
 #define BLURRILY_NEXT_VISIT(from_, out_)                                         \
   do {                                                                           \
     out_ = (from_);                                                              \
-    while (out_ < n_visit && min(tc, BLURRILY_WMT_AT(out_)) <                    \
-           matches_needed(ctl->thr, tc, BLURRILY_WIN_AT(out_) * kWindowRanks)) ++out_; \
+    while (out_ < n_visit) {                                                     \
+      uint32_t m_;                                                               \
+      BLURRILY_WMT_AT(out_, m_);                                                 \
+      if (min(tc, m_) >= matches_needed(ctl->thr, tc, BLURRILY_STEP_AT(out_) * kWPS * kWindowRanks)) break; \
+      ++out_;                                                                    \
+    }                                                                            \
   } while (0)
-#define BLURRILY_FETCH_TABLE(w_, A0, B0)                                         \
+#define BLURRILY_FETCH_TABLE(p_, A0, B0)                                         \
   do {                                                                           \
     A0 = B0 = 0;                                                                 \
-    if ((w_) < w1 && own) {                                                      \
-      const uint32_t idx_ = (w_) * kNumCodes + code;                             \
+    const uint32_t w_ = (p_) * kWPS + my_half;                                   \
+    if (w_ < w1 && own) {                                                        \
+      const uint32_t idx_ = w_ * kNumCodes + code;                               \
       A0 = A.slice_off[idx_]; B0 = A.slice_off[idx_ + 1];                        \
     }                                                                            \
   } while (0)
@@ -688,51 +792,70 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     } else {                                                                     \
       uint32_t at_ = incl_ - units_;                                             \
       for (uint32_t j_ = 0; j_ < units_; ++j_, ++at_)                            \
-        ring->desc[s_][at_] = make_uint2(ta + j_ * 512, tb);                     \
+        ring->desc[s_][at_] = make_uint2((ta + j_ * 512) | my_half, tb);         \
       if (lane == 0) ring->n_units[s_] = total_;                                 \
     }                                                                            \
+  } while (0)
+  // one published unit: the lane's 16-byte group of it, and the parity of its window
+#define BLURRILY_LOAD_UNIT(s_, k_, U, H)                                         \
+  do {                                                                           \
+    const uint2 d_ = ring->desc[s_][k_];                                         \
+    const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                    \
+    H = x_ & 1u;                                                                 \
+    U = load_group(A.ent, (x_ & ~7u) + lane * 8, __builtin_amdgcn_readfirstlane(d_.y)); \
   } while (0)
   // heads of this wave for ring slot s_: units wid, wid+kNW, ... (at most KP)
 #define BLURRILY_LOAD_HEADS(s_, n_)                                              \
   do {                                                                           \
     u0 = u1 = u2 = u3 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);      \
+    h0 = h1 = h2 = h3 = 0;                                                       \
     if ((n_) != kRingOverflow) {                                                 \
-      if (wid < (n_))           { const uint2 d_ = ring->desc[s_][wid];           u0 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
-      if (KP > 1 && wid + kNW < (n_))     { const uint2 d_ = ring->desc[s_][wid + kNW];     u1 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
-      if (KP > 2 && wid + 2 * kNW < (n_)) { const uint2 d_ = ring->desc[s_][wid + 2 * kNW]; u2 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
-      if (KP > 3 && wid + 3 * kNW < (n_)) { const uint2 d_ = ring->desc[s_][wid + 3 * kNW]; u3 = load_group(A.ent, d_.x + lane * 8, d_.y); } \
+      if (wid < (n_))                     BLURRILY_LOAD_UNIT(s_, wid, u0, h0);           \
+      if (KP > 1 && wid + kNW < (n_))     BLURRILY_LOAD_UNIT(s_, wid + kNW, u1, h1);     \
+      if (KP > 2 && wid + 2 * kNW < (n_)) BLURRILY_LOAD_UNIT(s_, wid + 2 * kNW, u2, h2); \
+      if (KP > 3 && wid + 3 * kNW < (n_)) BLURRILY_LOAD_UNIT(s_, wid + 3 * kNW, u3, h3); \
     }                                                                            \
   } while (0)
   // units of ring slot s_ from the first_-th unit of this wave on, loaded and counted in place
 #define BLURRILY_COUNT_FROM(s_, n_, first_)                                      \
   do {                                                                           \
     uint4 pend_ = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);            \
+    uint32_t pend_h_ = 0;                                                        \
     for (uint32_t k_ = wid + (first_) * kNW; k_ < (n_); k_ += kNW) {             \
-      const uint2 d_ = ring->desc[s_][k_];                                       \
-      const uint4 v_ = load_group(A.ent, d_.x + lane * 8, d_.y);                 \
-      bump8<CT>(cnt32, pend_);                                                   \
-      pend_ = v_;                                                                \
+      uint4 v_; uint32_t vh_;                                                    \
+      BLURRILY_LOAD_UNIT(s_, k_, v_, vh_);                                       \
+      bump_unit<CT>(cnt32, pend_, pend_h_);                                      \
+      pend_ = v_; pend_h_ = vh_;                                                 \
     }                                                                            \
-    bump8<CT>(cnt32, pend_);                                                     \
+    bump_unit<CT>(cnt32, pend_, pend_h_);                                        \
   } while (0)
-
-  uint4 u0, u1, u2, u3;
-  uint32_t ta = 0, tb = 0;                                      // table this wave will publish next
-  PHASE_DECL;
-  uint32_t i_cur = 0, i_next, i_next2;
+  // more units than the ring holds: every wave walks the table of step p_ itself
+#define BLURRILY_COUNT_WALK(p_)                                                  \
+  do {                                                                           \
+    uint32_t fa_, fb_, k_ = 0;                                                   \
+    BLURRILY_FETCH_TABLE(p_, fa_, fb_);                                          \
+    BLURRILY_FOR_SLOT_UNITS(kNW, fa_, fb_, wid, lane, k_,                        \
+                            { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), kNib ? (t_ >> 4) : 0u); }); \
+  } while (0)
 #if BLURRILY_COOP_ROTATE
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
 #else
 #define BLURRILY_PRODUCER(e_) (kNW - 1)                        /* units go round robin: the last wave has the fewest */
 #endif
-  // prologue: the producer publishes the first window, everyone agrees on the second
+
+  uint4 u0, u1, u2, u3;
+  uint32_t h0, h1, h2, h3;                                      // window parity of the heads (uniform)
+  uint32_t ta = 0, tb = 0;                                      // table this wave will publish next
+  PHASE_DECL;
+  uint32_t i_cur = 0, i_next, i_next2;
+  // prologue: one wave publishes the first step, everyone agrees on the second
   if (wid == BLURRILY_PRODUCER(0u)) {
-    BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(0u), ta, tb);
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb);
     BLURRILY_PRODUCE(0u, ta, tb);
   }
   __syncthreads();
   BLURRILY_NEXT_VISIT(1u, i_next);
-  if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(i_next), ta, tb);
+  if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next), ta, tb);
   {
     const uint32_t n0 = ring->n_units[0];
     BLURRILY_LOAD_HEADS(0u, n0);
@@ -740,43 +863,41 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 
   for (uint32_t e = 0; i_cur < n_visit; ++e) {
     const uint32_t s = e & 1;
-    const uint32_t w = BLURRILY_WIN_AT(i_cur);
-    const uint32_t wbase = w * kWindowRanks;
-    const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+    const uint32_t p = BLURRILY_STEP_AT(i_cur);
+    const uint32_t wbase = p * kWPS * kWindowRanks;
+    const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
     const uint32_t n_units = ring->n_units[s];
     PHASE_MARK(0);                                              // loop overhead
-    // ---- count window w ------------------------------------------------------------------
-    if (n_units == kRingOverflow) {                             // too many units for the ring: walk the table
-      uint32_t fa, fb;
-      BLURRILY_FETCH_TABLE(w, fa, fb);
-      count_rest<CT, kNW>(A.ent, cnt32, fa, fb, 0u, 0u, false, wid, lane, 0u);
+    // ---- count step p --------------------------------------------------------------------
+    if (n_units == kRingOverflow) {
+      BLURRILY_COUNT_WALK(p);
     } else if (n_units) {
       PHASE_UNIT(u0);
       if (KP > 1) PHASE_UNIT(u1);
       if (KP > 2) PHASE_UNIT(u2);
       if (KP > 3) PHASE_UNIT(u3);
-      bump8<CT>(cnt32, u0);
-      if (KP > 1) bump8<CT>(cnt32, u1);
-      if (KP > 2) bump8<CT>(cnt32, u2);
-      if (KP > 3) bump8<CT>(cnt32, u3);
+      bump_unit<CT>(cnt32, u0, h0);
+      if (KP > 1) bump_unit<CT>(cnt32, u1, h1);
+      if (KP > 2) bump_unit<CT>(cnt32, u2, h2);
+      if (KP > 3) bump_unit<CT>(cnt32, u3, h3);
       PHASE_MARK(1);                                            // head counted
       if (n_units > wid + KP * kNW) BLURRILY_COUNT_FROM(s, n_units, uint32_t(KP));
     }
     PHASE_MARK(2);                                              // rest counted
-    // the producer publishes the next visited window (its table arrived a step ago)
+    // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
     if (wid == BLURRILY_PRODUCER(e + 1)) {
       if (i_next < n_visit) BLURRILY_PRODUCE(s ^ 1u, ta, tb);
       else if (lane == 0) ring->n_units[s ^ 1u] = 0;
     }
-    PHASE_MARK(7);                                              // (producer turn) next window's units published
+    PHASE_MARK(7);                                              // (producer turn) next step's units published
     __syncthreads();                                            // counts and next descriptors visible
     PHASE_MARK(3);                                              // barrier after count
-    // ---- next window's heads in flight during the scan; decide the window after it --------
+    // ---- next step's heads in flight during the scan; decide the step after it -------------
     const uint32_t n_next = ring->n_units[s ^ 1u];
     BLURRILY_LOAD_HEADS(s ^ 1u, n_next);
     BLURRILY_NEXT_VISIT(i_next + 1, i_next2);                   // uniform: thr only changes behind select's barriers
-    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(i_next2), ta, tb);
-    PHASE_MARK(4);                                              // next heads issued, window after chosen
+    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb);
+    PHASE_MARK(4);                                              // next heads issued, step after chosen
     if (n_units) {
       for (;;) {
         scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
@@ -784,13 +905,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
         if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
-        if (n_units == kRingOverflow) {                         // pool overflow: sweep window w again
-          uint32_t fa, fb;
-          BLURRILY_FETCH_TABLE(w, fa, fb);
-          count_rest<CT, kNW>(A.ent, cnt32, fa, fb, 0u, 0u, false, wid, lane, 0u);
-        } else {
-          BLURRILY_COUNT_FROM(s, n_units, 0u);
-        }
+        if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
+        else BLURRILY_COUNT_FROM(s, n_units, 0u);
         __syncthreads();
       }
     }
@@ -800,13 +916,15 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   PHASE_FLUSH(A);
   __syncthreads();                                              // ring and ctl quiet before the needle ends
 #undef BLURRILY_PRODUCER
+#undef BLURRILY_COUNT_WALK
 #undef BLURRILY_COUNT_FROM
 #undef BLURRILY_LOAD_HEADS
+#undef BLURRILY_LOAD_UNIT
 #undef BLURRILY_PRODUCE
 #undef BLURRILY_FETCH_TABLE
 #undef BLURRILY_NEXT_VISIT
 #undef BLURRILY_WMT_AT
-#undef BLURRILY_WIN_AT
+#undef BLURRILY_STEP_AT
 }
 
 // RANGED = latency mode (a needle's windows cut into ranges); a separate instantiation so the
@@ -881,8 +999,11 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
-    if constexpr (SHORT && !RANGED && BLURRILY_COOP) {                                                            \
-      sweep_coop<CT, NT, BLURRILY_COOP_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_);    \
+    if constexpr (SHORT && !RANGED && BLURRILY_COOP) {                                                  \
+      if (BLURRILY_NIBBLE && nd.T <= 15)  /* 4-bit counters: two windows per step */                    \
+        sweep_coop<Nib, NT, BLURRILY_COOP_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
+      else                                                                                              \
+        sweep_coop<CT, NT, BLURRILY_COOP_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
     } else if constexpr (SHORT) {                                                                       \
       sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
