@@ -58,9 +58,6 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_COOP_ROTATE
 #define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
 #endif
-#ifndef BLURRILY_COOP_HEAD_UNITS
-#define BLURRILY_COOP_HEAD_UNITS 2     // sweep_coop: units per wave of the next window in flight during the scan
-#endif
 #ifndef BLURRILY_HEAD_UNITS
 #define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
 #endif
@@ -720,10 +717,13 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // In sweep_pipelined every wave walks the needle's slice table itself to find its units: sixteen
 // times the same work.  Here ONE wave per step (rotating) cuts the slices of the next visited
 // window into units and publishes them as descriptors {first entry, slice end} in an LDS ring;
-// after the step's first barrier every wave just reads the descriptors of its units (unit k
-// belongs to wave k mod kNW).  The next visited window is decided one step ahead (windows that
-// cannot hold a candidate are stepped over without a barrier), so the producing wave has the
-// table in registers before it needs it.
+// in the next step every wave just reads the descriptors of its units (unit k belongs to wave
+// k mod kNW) and streams them, one unit's LDS atomics running under the next unit's load.
+// (Loading units a step ahead, during the scan, was measured and bought nothing: 0, 1 or 2
+// units in flight are equal within noise, 3 or 4 cost 7-11% -- the registers are worth more.)
+// The next visited window is decided one step ahead (windows that cannot hold a candidate are
+// stepped over without a barrier), so the producing wave has the table in registers before it
+// needs it.
 constexpr uint32_t kRingUnits = 256;                            // descriptors per ring slot
 struct UnitRing {
   uint2    desc[2][kRingUnits];                                 // .x first entry of the unit, .y end of its slice
@@ -731,7 +731,7 @@ struct UnitRing {
 };
 constexpr uint32_t kRingOverflow = 0xFFFFFFFFu;
 
-template <typename CT, int NT, int KP>
+template <typename CT, int NT>
 __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
                            unsigned long long* pool, Control* ctl, UnitRing* ring, const uint32_t w0,
                            const uint32_t w1, const uint32_t ws) {
@@ -804,24 +804,13 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     H = x_ & 1u;                                                                 \
     U = load_group(A.ent, (x_ & ~7u) + lane * 8, __builtin_amdgcn_readfirstlane(d_.y)); \
   } while (0)
-  // heads of this wave for ring slot s_: units wid, wid+kNW, ... (at most KP)
-#define BLURRILY_LOAD_HEADS(s_, n_)                                              \
-  do {                                                                           \
-    u0 = u1 = u2 = u3 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);      \
-    h0 = h1 = h2 = h3 = 0;                                                       \
-    if ((n_) != kRingOverflow) {                                                 \
-      if (wid < (n_))                     BLURRILY_LOAD_UNIT(s_, wid, u0, h0);           \
-      if (KP > 1 && wid + kNW < (n_))     BLURRILY_LOAD_UNIT(s_, wid + kNW, u1, h1);     \
-      if (KP > 2 && wid + 2 * kNW < (n_)) BLURRILY_LOAD_UNIT(s_, wid + 2 * kNW, u2, h2); \
-      if (KP > 3 && wid + 3 * kNW < (n_)) BLURRILY_LOAD_UNIT(s_, wid + 3 * kNW, u3, h3); \
-    }                                                                            \
-  } while (0)
-  // units of ring slot s_ from the first_-th unit of this wave on, loaded and counted in place
-#define BLURRILY_COUNT_FROM(s_, n_, first_)                                      \
+  // the units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
+  // atomics run while the next unit's load is in flight
+#define BLURRILY_COUNT_UNITS(s_, n_)                                             \
   do {                                                                           \
     uint4 pend_ = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);            \
     uint32_t pend_h_ = 0;                                                        \
-    for (uint32_t k_ = wid + (first_) * kNW; k_ < (n_); k_ += kNW) {             \
+    for (uint32_t k_ = wid; k_ < (n_); k_ += kNW) {                              \
       uint4 v_; uint32_t vh_;                                                    \
       BLURRILY_LOAD_UNIT(s_, k_, v_, vh_);                                       \
       bump_unit<CT>(cnt32, pend_, pend_h_);                                      \
@@ -843,8 +832,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #define BLURRILY_PRODUCER(e_) (kNW - 1)                        /* units go round robin: the last wave has the fewest */
 #endif
 
-  uint4 u0, u1, u2, u3;
-  uint32_t h0, h1, h2, h3;                                      // window parity of the heads (uniform)
   uint32_t ta = 0, tb = 0;                                      // table this wave will publish next
   PHASE_DECL;
   uint32_t i_cur = 0, i_next, i_next2;
@@ -856,10 +843,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   __syncthreads();
   BLURRILY_NEXT_VISIT(1u, i_next);
   if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next), ta, tb);
-  {
-    const uint32_t n0 = ring->n_units[0];
-    BLURRILY_LOAD_HEADS(0u, n0);
-  }
 
   for (uint32_t e = 0; i_cur < n_visit; ++e) {
     const uint32_t s = e & 1;
@@ -871,19 +854,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     // ---- count step p --------------------------------------------------------------------
     if (n_units == kRingOverflow) {
       BLURRILY_COUNT_WALK(p);
-    } else if (n_units) {
-      PHASE_UNIT(u0);
-      if (KP > 1) PHASE_UNIT(u1);
-      if (KP > 2) PHASE_UNIT(u2);
-      if (KP > 3) PHASE_UNIT(u3);
-      bump_unit<CT>(cnt32, u0, h0);
-      if (KP > 1) bump_unit<CT>(cnt32, u1, h1);
-      if (KP > 2) bump_unit<CT>(cnt32, u2, h2);
-      if (KP > 3) bump_unit<CT>(cnt32, u3, h3);
-      PHASE_MARK(1);                                            // head counted
-      if (n_units > wid + KP * kNW) BLURRILY_COUNT_FROM(s, n_units, uint32_t(KP));
+    } else {
+      BLURRILY_COUNT_UNITS(s, n_units);
     }
-    PHASE_MARK(2);                                              // rest counted
+    PHASE_MARK(2);                                              // units counted
     // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
     if (wid == BLURRILY_PRODUCER(e + 1)) {
       if (i_next < n_visit) BLURRILY_PRODUCE(s ^ 1u, ta, tb);
@@ -892,12 +866,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     PHASE_MARK(7);                                              // (producer turn) next step's units published
     __syncthreads();                                            // counts and next descriptors visible
     PHASE_MARK(3);                                              // barrier after count
-    // ---- next step's heads in flight during the scan; decide the step after it -------------
-    const uint32_t n_next = ring->n_units[s ^ 1u];
-    BLURRILY_LOAD_HEADS(s ^ 1u, n_next);
+    // ---- decide the step after the next; its table travels during the scan -------------------
     BLURRILY_NEXT_VISIT(i_next + 1, i_next2);                   // uniform: thr only changes behind select's barriers
     if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb);
-    PHASE_MARK(4);                                              // next heads issued, step after chosen
+    PHASE_MARK(4);                                              // step after the next chosen
     if (n_units) {
       for (;;) {
         scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
@@ -906,7 +878,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
         PHASE_MARK(6);                                          // barrier after scan
         if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
         if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
-        else BLURRILY_COUNT_FROM(s, n_units, 0u);
+        else BLURRILY_COUNT_UNITS(s, n_units);
         __syncthreads();
       }
     }
@@ -917,8 +889,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   __syncthreads();                                              // ring and ctl quiet before the needle ends
 #undef BLURRILY_PRODUCER
 #undef BLURRILY_COUNT_WALK
-#undef BLURRILY_COUNT_FROM
-#undef BLURRILY_LOAD_HEADS
+#undef BLURRILY_COUNT_UNITS
 #undef BLURRILY_LOAD_UNIT
 #undef BLURRILY_PRODUCE
 #undef BLURRILY_FETCH_TABLE
@@ -1001,9 +972,9 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
   do {                                                                                                  \
     if constexpr (SHORT && !RANGED && BLURRILY_COOP) {                                                  \
       if (BLURRILY_NIBBLE && nd.T <= 15)  /* 4-bit counters: two windows per step */                    \
-        sweep_coop<Nib, NT, BLURRILY_COOP_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
+        sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
       else                                                                                              \
-        sweep_coop<CT, NT, BLURRILY_COOP_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
+        sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
     } else if constexpr (SHORT) {                                                                       \
       sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
