@@ -11,7 +11,7 @@ def summarise(path, only=None):
                      "from counters_collection group by kernel_name, counter_name").fetchall()
     out = {}
     for k, n, v, disp, dur in rows:
-        short = k.split("(")[0].replace("void ", "").replace("blurrily::(anonymous namespace)::", "")
+        short = k.replace("void ", "").replace("blurrily::(anonymous namespace)::", "").split("(")[0]
         if only and only not in short:
             continue
         out.setdefault(short, {})[n] = (v, disp, dur)
