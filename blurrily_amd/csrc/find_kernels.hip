@@ -162,7 +162,7 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
 // 19 683 reachable codes so 15 bits always suffice).
 template <typename CT> struct Packing;
 template <> struct Packing<uint8_t> {
-  static constexpr uint32_t kPerWord = 4, kBits = 8, kLog = 2, kHi = 0x80808080u, kOnes = 0x01010101u,
+  static constexpr uint32_t kPerWord = 4, kBits = 8, kHi = 0x80808080u, kOnes = 0x01010101u,
                             kTop = 0x80u, kMask = 0xFFu;
 };
 template <> struct Packing<uint16_t> {
@@ -172,8 +172,11 @@ template <> struct Packing<uint16_t> {
 
 // 4-bit counters for needles with at most 15 distinct trigrams (two needles in three at
 // Geonames scale): the same 64 KiB of LDS then hold TWO windows, so a sweep takes half the steps.
-// Counter index = (window parity << 16) | in-window rank; the two padding slots (0xFFFF of either
-// half) are the top nibble of their word, so their overflow leaves the word.
+// In-window rank r keeps its byte-counter address (word r >> 2, byte r & 3); the even window
+// of the step counts in the low nibble of that byte, the odd one in the high nibble -- so a
+// posting costs the same instructions as with byte counters, the increment being 1 or 16 shifted
+// by the byte position.  Both nibbles of the padding slot 0xFFFF sit in the top byte of the
+// last word: their overflow leaves the word.
 struct Nib {};
 template <> struct Packing<Nib> {
   static constexpr uint32_t kPerWord = 8, kBits = 4, kMask = 0xFu;
@@ -217,18 +220,18 @@ template <> struct ScanTraits<Nib> {
   static __device__ __forceinline__ uint32_t any_hit(uint4 v, Need n) {
     return hits(v.x, n) | hits(v.y, n) | hits(v.z, n) | hits(v.w, n);
   }
-  // counter indices in use: [0, wlen) for one window, [0, 65536 + wlen - 65535) for two
-  static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) {
-    return ((wlen <= kWindowRanks ? wlen : wlen + 1) + 31) / 32;
-  }
+  // bytes in use: in-window ranks [0, min(wlen, one window)) -- the odd window is never longer than the even one
+  static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) { return (min(wlen, kWindowRanks) + 15) / 16; }
   static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t i) {
-    if ((i & (kVecs / 2 - 1)) == kVecs / 2 - 1) v.w &= 0x0FFFFFFFu;   // slots 0xFFFF and 0x1FFFF count padding
+    if (i == kVecs - 1) v.w &= 0x00FFFFFFu;                         // slot 0xFFFF of both windows counts padding
     return v;
   }
-  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) { return wbase + idx - (idx >> 16); }
+  // counter index = 8 * word + nibble; nibble = 2 * (byte in word) + (window parity)
+  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
+    return wbase + (idx & 1u) * kWindowRanks + (idx >> 1);
+  }
   static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
-    if (nv < kVecs / 2 && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 2 - 1] = 0;
-    if (nv < kVecs && tid == 1) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+    if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
   }
 };
 
@@ -243,12 +246,35 @@ struct Control {            // workgroup-shared scalars
   uint32_t tally;           // scratch of cold_start_need
 };
 
+// One posting = one relaxed LDS atomic (result unused -> ds_add_u32) on the word holding the
+// rank's counter.  The address and the increment are formed in three instructions per posting: and (address), shift (bit position; the hardware
+// uses the low five bits of a shift amount), shift (increment).  For the rank in the high half
+// of a loaded dword the first two read that half directly (SDWA operand select).
 template <typename CT>
 __device__ __forceinline__ void bump(uint32_t* cnt32, uint32_t r) {
   using P = Packing<CT>;
-  // one relaxed LDS atomic per posting; result unused -> ds_add_u32
   __hip_atomic_fetch_add(&cnt32[r >> P::kLog], 1u << ((r & (P::kPerWord - 1)) * P::kBits),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// (rank in the high half of v) << SH, in one instruction
+template <uint32_t SH>
+__device__ __forceinline__ uint32_t hi_half_shl(uint32_t v) {
+  uint32_t out;
+  const uint32_t sh = SH;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+      : "=v"(out) : "v"(sh), "v"(v));
+  return out;
+}
+
+// byte counters (ONE = 1) and 4-bit counters (ONE = 1: even window of the step, 16: odd window):
+// both ranks of a dword
+template <uint32_t ONE>
+__device__ __forceinline__ void bump_pair_bytes(uint32_t* cnt32, uint32_t v) {
+  __hip_atomic_fetch_add(&cnt32[(v & 0xFFFFu) >> 2], ONE << ((v << 3) & 24u), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(&cnt32[v >> 18], ONE << (hi_half_shl<3>(v) & 24u), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // Count one 16-byte group: eight 16-bit in-window ranks, every one of them either a real
@@ -260,28 +286,29 @@ __device__ __forceinline__ bool group_live(const uint4 v) { return (v.x & 0xFFFF
 template <typename CT>
 __device__ __forceinline__ void bump8(uint32_t* cnt32, const uint4 v) {
   if (!group_live(v)) return;
-  bump<CT>(cnt32, v.x & 0xFFFFu); bump<CT>(cnt32, v.x >> 16);
-  bump<CT>(cnt32, v.y & 0xFFFFu); bump<CT>(cnt32, v.y >> 16);
-  bump<CT>(cnt32, v.z & 0xFFFFu); bump<CT>(cnt32, v.z >> 16);
-  bump<CT>(cnt32, v.w & 0xFFFFu); bump<CT>(cnt32, v.w >> 16);
+  if constexpr (sizeof(CT) == 1) {
+    bump_pair_bytes<1>(cnt32, v.x); bump_pair_bytes<1>(cnt32, v.y);
+    bump_pair_bytes<1>(cnt32, v.z); bump_pair_bytes<1>(cnt32, v.w);
+  } else {
+    bump<CT>(cnt32, v.x & 0xFFFFu); bump<CT>(cnt32, v.x >> 16);
+    bump<CT>(cnt32, v.y & 0xFFFFu); bump<CT>(cnt32, v.y >> 16);
+    bump<CT>(cnt32, v.z & 0xFFFFu); bump<CT>(cnt32, v.z >> 16);
+    bump<CT>(cnt32, v.w & 0xFFFFu); bump<CT>(cnt32, v.w >> 16);
+  }
 }
 
-// 4-bit flavour: HALF = parity of the unit's window (compile-time, so it lands in the ds_add's
-// immediate offset)
-template <uint32_t HALF>
-__device__ __forceinline__ void bump_nib(uint32_t* cnt32, uint32_t r) {
-  __hip_atomic_fetch_add(&cnt32[HALF * (kWindowSize / 8) + (r >> 3)], 1u << ((r & 7u) * 4),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+// 4-bit flavour: HALF = parity of the unit's window within the step
 template <uint32_t HALF>
 __device__ __forceinline__ void bump8_nib(uint32_t* cnt32, const uint4 v) {
   if (!group_live(v)) return;
-  bump_nib<HALF>(cnt32, v.x & 0xFFFFu); bump_nib<HALF>(cnt32, v.x >> 16);
-  bump_nib<HALF>(cnt32, v.y & 0xFFFFu); bump_nib<HALF>(cnt32, v.y >> 16);
-  bump_nib<HALF>(cnt32, v.z & 0xFFFFu); bump_nib<HALF>(cnt32, v.z >> 16);
-  bump_nib<HALF>(cnt32, v.w & 0xFFFFu); bump_nib<HALF>(cnt32, v.w >> 16);
+  constexpr uint32_t kOne = HALF ? 16u : 1u;
+  bump_pair_bytes<kOne>(cnt32, v.x); bump_pair_bytes<kOne>(cnt32, v.y);
+  bump_pair_bytes<kOne>(cnt32, v.z); bump_pair_bytes<kOne>(cnt32, v.w);
 }
-// count one unit; `half` (uniform) = parity of its window, used by the 4-bit flavour only
+// count one unit; `half` (uniform) = parity of its window, used by the 4-bit flavour only.
+// (Reading the short last unit of a slice with four or two ranks per lane -- fewer, fuller
+// atomic instructions -- was measured: 17% slower.  The LDS atomics cost by lane and by bank
+// conflict, not by instruction, and the narrow reads undo the bank-aware dealing.)
 template <typename CT>
 __device__ __forceinline__ void bump_unit(uint32_t* cnt32, const uint4 v, uint32_t half) {
   if constexpr (std::is_same<CT, Nib>::value) {
@@ -380,6 +407,8 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       };
       word(v.x, 0); word(v.y, 1); word(v.z, 2); word(v.w, 3);
     };
+    // (Taking a thread's vectors two at a time -- reads in flight together, one zero quad --
+    // was measured 3.5% slower than this plain loop.)
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint4 v = cnt128[i];
       // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held

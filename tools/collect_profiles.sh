@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 python $root/bench.py > $out/bench_geonames.json 2> $out/bench_geonames.log
 python $root/bench.py --workload words --no-cpu-baseline > $out/bench_words.json 2> $out/bench_words.log
 python $root/bench.py --workload skewed --no-cpu-baseline > $out/bench_skewed.json 2> $out/bench_skewed.log
-rocprofv3 --kernel-trace --stats -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline > $out/stats_bench.json 2> $out/stats_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline > $out/stats_bench.json 2> $out/stats_bench.log
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   mkdir -p $out/pmc_$name
