@@ -407,8 +407,8 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       };
       word(v.x, 0); word(v.y, 1); word(v.z, 2); word(v.w, 3);
     };
-    // (Taking a thread's vectors two at a time -- reads in flight together, one zero quad --
-    // was measured 3.5% slower than this plain loop.)
+    // (Measured alternatives: a thread's vectors two at a time -- reads in flight together, one
+    // zero quad -- 3.5% slower; read-and-clear in one ds_wrxchg_rtn_b64 per 8 bytes: +0.5%, noise.)
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint4 v = cnt128[i];
       // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held
