@@ -3,7 +3,9 @@
 Fails loudly when the library is missing: there is no pure-Python or CPU path.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BLURRILY_LIB selects another build of the same library (the phase-profile build of tools/)
@@ -33,6 +35,36 @@ class DeviceInfo(C.Structure):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must run on ONE copy of the HIP runtime.  PyTorch-ROCm ships its own
+    libamdhip64.so.7 and loads it by path; if this library came first, bound to /opt/rocm's copy,
+    the two runtimes would not see each other's streams and device pointers (torch tensors handed to
+    blurrily_storage_find_batch_device, as bench.py does).  The dynamic linker resolves our
+    DT_NEEDED by soname against what is already loaded, so: when torch is installed but not yet
+    imported, load its copy first -- whichever order the application imports things in, everybody
+    then shares it.  torch itself is not imported."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def hip_runtime():
+    """ctypes handle of the HIP runtime the library is bound to (tests allocate through it)."""
+    lib()
+    return C.CDLL("libamdhip64.so.7")
+
+
 def lib():
     """Load the shared library once; raise if it has not been built."""
     global _lib
@@ -42,6 +74,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  blurrily_amd has no CPU fallback.")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH, use_errno=True)
     vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
     sig = {
@@ -60,6 +93,10 @@ def lib():
         "blurrily_storage_find_batch_device": (C.c_int, [vp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                          C.c_uint16, C.c_void_p, C.c_void_p, C.c_void_p,
                                                          C.c_void_p]),
+        "blurrily_storage_find_batch_raw": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint16,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+        "blurrily_normalize_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p]),
         "blurrily_storage_sync_device": (C.c_int, [vp]),
         "blurrily_tokeniser_parse_string": (C.c_int, [C.c_char_p, C.c_void_p]),
         "blurrily_storage_device_info": (C.c_int, [vp, C.POINTER(DeviceInfo)]),
@@ -77,6 +114,7 @@ EXPORTED_SYMBOLS = (
     "blurrily_storage_new", "blurrily_storage_load", "blurrily_storage_close", "blurrily_storage_mark",
     "blurrily_storage_save", "blurrily_storage_put", "blurrily_storage_delete", "blurrily_storage_find",
     "blurrily_storage_stats", "blurrily_storage_put_many", "blurrily_storage_find_batch",
-    "blurrily_storage_find_batch_device", "blurrily_storage_sync_device", "blurrily_tokeniser_parse_string",
+    "blurrily_storage_find_batch_device", "blurrily_storage_find_batch_raw", "blurrily_normalize_batch_device",
+    "blurrily_storage_sync_device", "blurrily_tokeniser_parse_string",
     "blurrily_storage_device_info", "blurrily_storage_set_timing",
 )

@@ -429,8 +429,12 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
                   true, static_cast<hipStream_t>(stream));
 }
 
-int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_t* offsets, size_t n,
-                                uint16_t limit, trigram_match results, uint32_t* counts) {
+}  // extern "C"
+
+// Host-buffer batch: needles in, rows out.  raw = the needles are un-normalised ASCII (see
+// blurrily_storage_find_batch_raw); non_ascii (raw only, may be null) receives the per-needle flags.
+static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
+                           trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii) {
   if (n == 0) return 0;
   // what the reference's find does first: tokenise, sort the needle's dirty buckets
   size_t max_len = 0;
@@ -442,12 +446,14 @@ int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_
     const void* nul = std::memchr(s, 0, cap);
     const size_t len = nul ? size_t(static_cast<const char*>(nul) - s) : cap;
     max_len = std::max(max_len, len);
-    if (any_dirty) {
+    if (any_dirty && !raw) {
       codes.resize(len + 1);
       const int nt = tokenise(s, len, codes.data());
       for (int k = 0; k < nt; ++k) m->host->sort_bucket_if_dirty(codes[k]);
     }
   }
+  // (raw needles are only normalised on the device: sort every dirty bucket, as the device entry does)
+  if (any_dirty && raw) m->host->sort_dirty_buckets();
   if (ensure_device(m) < 0) return -1;
   if (m->timing && !m->ev[0])
     for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
@@ -459,14 +465,16 @@ int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_
   const size_t cnt_bytes = n * sizeof(uint32_t);
   // one device block in ([offsets | needles]) and one out ([counts | rows])
   const size_t in_bytes = align_up(off_bytes, 256) + std::max<size_t>(packed_bytes, 16);
-  const size_t out_bytes = align_up(cnt_bytes, 256) + std::max<size_t>(row_bytes, 16);
+  const size_t flag_bytes = raw ? align_up(cnt_bytes, 256) : 0;          // [counts | flags | rows]
+  const size_t out_bytes = align_up(cnt_bytes, 256) + flag_bytes + std::max<size_t>(row_bytes, 16);
   if (m->ws_io_in.reserve(in_bytes, stream) < 0 || m->ws_io_out.reserve(out_bytes, stream) < 0) return -1;
   unsigned char* d_in = static_cast<unsigned char*>(m->ws_io_in.p);
   unsigned char* d_out = static_cast<unsigned char*>(m->ws_io_out.p);
   const uint64_t* d_offsets = reinterpret_cast<const uint64_t*>(d_in);
-  const char* d_packed = reinterpret_cast<const char*>(d_in + align_up(off_bytes, 256));
+  char* d_packed = reinterpret_cast<char*>(d_in + align_up(off_bytes, 256));
   uint32_t* d_counts = reinterpret_cast<uint32_t*>(d_out);
-  trigram_match d_rows = reinterpret_cast<trigram_match>(d_out + align_up(cnt_bytes, 256));
+  uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_out + align_up(cnt_bytes, 256));
+  trigram_match d_rows = reinterpret_cast<trigram_match>(d_out + align_up(cnt_bytes, 256) + flag_bytes);
 
   // Small batches (the single blurrily_storage_find above all) go through pinned staging: one
   // copy in, one copy out, instead of four pageable ones.
@@ -483,6 +491,7 @@ int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_
       BLURRILY_HIP_TRY(hipMemcpyAsync(d_in + align_up(off_bytes, 256), packed, packed_bytes, hipMemcpyHostToDevice,
                                       stream));
   }
+  if (raw && launch_normalise(d_packed, d_offsets, uint32_t(n), d_packed, d_flags, stream) < 0) return -1;
   if (run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_rows, d_counts, nullptr, max_len > 126,
                max_len > 63, stream) < 0)
     return -1;
@@ -491,13 +500,40 @@ int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_
     BLURRILY_HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
     BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
     std::memcpy(counts, h_out, cnt_bytes);
-    if (limit) std::memcpy(results, h_out + align_up(cnt_bytes, 256), row_bytes);
+    if (raw && non_ascii) std::memcpy(non_ascii, h_out + align_up(cnt_bytes, 256), cnt_bytes);
+    if (limit) std::memcpy(results, h_out + align_up(cnt_bytes, 256) + flag_bytes, row_bytes);
   } else {
     BLURRILY_HIP_TRY(hipMemcpyAsync(counts, d_counts, cnt_bytes, hipMemcpyDeviceToHost, stream));
+    if (raw && non_ascii) BLURRILY_HIP_TRY(hipMemcpyAsync(non_ascii, d_flags, cnt_bytes, hipMemcpyDeviceToHost, stream));
     if (limit) BLURRILY_HIP_TRY(hipMemcpyAsync(results, d_rows, row_bytes, hipMemcpyDeviceToHost, stream));
     BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
   }
   return 0;
+}
+
+extern "C" {
+
+int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_t* offsets, size_t n,
+                                uint16_t limit, trigram_match results, uint32_t* counts) {
+  return find_batch_host(m, packed, offsets, n, limit, results, counts, false, nullptr);
+}
+
+int blurrily_storage_find_batch_raw(trigram_map m, const char* packed, const uint64_t* offsets, size_t n,
+                                    uint16_t limit, trigram_match results, uint32_t* counts,
+                                    uint32_t* non_ascii) {
+  return find_batch_host(m, packed, offsets, n, limit, results, counts, true, non_ascii);
+}
+
+int blurrily_normalize_batch_device(const char* d_packed, const uint64_t* d_offsets, size_t n, char* d_out,
+                                    uint32_t* d_non_ascii, void* stream) {
+  if (n > 0xFFFFFFFFull) { errno = EINVAL; return -1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {   // no CPU fallback, here neither
+    std::fprintf(stderr, "blurrily_hip: no usable HIP device\n");
+    errno = ENODEV;
+    return -1;
+  }
+  return launch_normalise(d_packed, d_offsets, uint32_t(n), d_out, d_non_ascii, static_cast<hipStream_t>(stream));
 }
 
 int blurrily_storage_find(trigram_map haystack, const char* needle, uint16_t limit, trigram_match results) {

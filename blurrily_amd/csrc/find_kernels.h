@@ -66,6 +66,9 @@ uint32_t find_pool_cap(uint32_t keep);
 int find_threads();
 uint32_t find_wgs_per_cu();   // resident byte-counter workgroups per CU (LDS and wave limits)   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);
+// Blurrily::Map#normalize_string for ASCII needles, in place or not (find_kernels.hip: normalise_kernel)
+int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* out, uint32_t* non_ascii,
+                     hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
 // Merge, per needle, two result lists that are each in result order (base image and delta image

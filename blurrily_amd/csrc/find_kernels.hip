@@ -155,6 +155,60 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, two table slots per lane
 }
 
+// ------------------------------------------------------------ normaliser ---
+// Blurrily::Map#normalize_string (lib/blurrily/map.rb:40-47) for ASCII needles, one lane per
+// needle, byte for byte what the Ruby does:
+//   downcase; then, UNLESS some line of the needle is made of [a-z ] only (map.rb:42 -- Ruby's
+//   ^ and $ anchor at lines): every byte that is not a-z becomes ' ' (for ASCII input the NFKD
+//   step and the "delete non-ASCII" step are the identity); then runs of whitespace
+//   [ \t\n\v\f\r] are squeezed to one space and both ends stripped (trailing NULs too, as
+//   String#strip does).
+// The result is written at the needle's own offset -- never longer than the input,
+// NUL-terminated when shorter, which is where the tokeniser stops -- so `out` may alias `in`.
+// Needles holding a byte >= 0x80 are flagged: their NFKD decomposition is host work
+// (ActiveSupport's tables, Gemfile.lock:11).
+__device__ __forceinline__ bool dev_is_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+__global__ void normalise_kernel(const char* in, const uint64_t* __restrict__ offsets, uint32_t n, char* out,
+                                 uint32_t* __restrict__ non_ascii) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const uint64_t beg = offsets[q], end = offsets[q + 1];
+  // pass 1: is there a line of [a-z ]+ (after downcasing)?  any byte >= 0x80?
+  bool plain = false, line_ok = true;
+  uint64_t line_len = 0;
+  uint32_t high = 0;
+  for (uint64_t k = beg; k < end; ++k) {
+    unsigned char c = static_cast<unsigned char>(in[k]);
+    high |= c >> 7;
+    if (c == '\n') {
+      plain |= line_ok && line_len > 0;
+      line_ok = true; line_len = 0;
+      continue;
+    }
+    if (c >= 'A' && c <= 'Z') c += 'a' - 'A';
+    line_ok &= (c >= 'a' && c <= 'z') || c == ' ';
+    ++line_len;
+  }
+  plain |= line_ok && line_len > 0;
+  // pass 2: rewrite
+  uint64_t w = beg, keep = beg;        // keep: end of the text once trailing blanks / NULs are stripped
+  bool gap = false;                    // whitespace seen since the last byte written
+  for (uint64_t k = beg; k < end; ++k) {
+    unsigned char c = static_cast<unsigned char>(in[k]);
+    if (c >= 'A' && c <= 'Z') c += 'a' - 'A';
+    const bool letter = c >= 'a' && c <= 'z';
+    if (!plain && !letter) c = ' ';
+    if (dev_is_space(c)) { gap = true; continue; }
+    if (gap && w > beg) out[w++] = ' ';
+    gap = false;
+    out[w++] = static_cast<char>(c);
+    if (c != 0) keep = w;
+  }
+  if (keep < end) out[keep] = 0;
+  if (non_ascii) non_ascii[q] = high;
+}
+
 // ------------------------------------------------------------- find kernel ---
 
 // Packed LDS counters.  CT = uint8_t (needles with <= 127 distinct trigrams:
@@ -1202,6 +1256,16 @@ int launch_tokenise(const TokeniseArgs& t, hipStream_t stream) {
   hipLaunchKernelGGL(tokenise_kernel, dim3(grid), dim3(block), 0, stream, t.packed, t.offsets, t.n,
                      t.code_total, t.qcodes, t.q_ntri, t.q_nb, t.big_list, t.big_count, t.mid_list, t.mid_count,
                      t.start_win, t.q_start);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* out, uint32_t* non_ascii,
+                     hipStream_t stream) {
+  if (n == 0) return 0;
+  const uint32_t block = 128;
+  hipLaunchKernelGGL(normalise_kernel, dim3((n + block - 1) / block), dim3(block), 0, stream, in, offsets, n, out,
+                     non_ascii);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }

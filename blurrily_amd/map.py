@@ -175,6 +175,23 @@ class RawMap:
             _raise_errno()
         return rows[:, :limit, :], counts
 
+    def find_batch_raw_packed(self, packed, offsets, limit):
+        """find_batch_packed over un-normalised ASCII needles: normalize_string runs on the device
+        (blurrily_storage_find_batch_raw).  Returns (rows, counts, non_ascii[n] uint32)."""
+        self._check_open()
+        n = len(offsets) - 1
+        limit = int(limit) & 0xFFFF
+        rows = np.zeros((n, max(limit, 1), 3), dtype=np.uint32)
+        counts = np.zeros(n, dtype=np.uint32)
+        flags = np.zeros(n, dtype=np.uint32)
+        buf = np.frombuffer(packed, dtype=np.uint8) if not isinstance(packed, np.ndarray) else packed
+        res = self._lib.blurrily_storage_find_batch_raw(
+            self._h, buf.ctypes.data if buf.size else None, offsets.ctypes.data, n, limit,
+            rows.ctypes.data, counts.ctypes.data, flags.ctypes.data)
+        if res < 0:
+            _raise_errno()
+        return rows[:, :limit, :], counts, flags
+
     def sync_device(self):
         self._check_open()
         if self._lib.blurrily_storage_sync_device(self._h) < 0:
@@ -269,6 +286,14 @@ class Map(RawMap):
         limit = int(limit)
         if limit <= 0:
             limit = LIMIT_DEFAULT
-        packed, offsets = _pack([_as_bytes(normalize_string(s)) for s in needles])
-        rows, counts = self.find_batch_packed(packed, offsets, limit)
+        # ASCII needles go to the GPU as they are (normalize_string runs there); the others are
+        # normalised here first -- NFKD is host work -- and pass through the device step unchanged
+        raw = []
+        for s in needles:
+            b = _as_bytes(s)
+            raw.append(b if b.isascii() else _as_bytes(normalize_string(b.decode("utf-8", "replace")
+                                                                        if isinstance(s, bytes) else s)))
+        packed, offsets = _pack(raw)
+        rows, counts, flags = self.find_batch_raw_packed(packed, offsets, limit)
+        assert not flags.any()
         return [rows[i, :counts[i]].tolist() for i in range(len(needles))]

@@ -116,6 +116,25 @@ int blurrily_storage_find_batch_device(trigram_map haystack, const char* d_packe
                                        trigram_match d_results, uint32_t* d_counts,
                                        uint32_t* d_nb_entries, void* stream);
 
+/* Needle normalisation on the device -- Blurrily::Map#normalize_string
+ * (lib/blurrily/map.rb:40-47) for ASCII needles: A-Z -> a-z, every other byte
+ * that is not a-z -> ' ', runs of spaces squeezed, ends stripped.  The result is
+ * written to `d_out` at the needle's own offset (never longer than the input;
+ * NUL-terminated when shorter), so `d_out` may be `d_packed` and the buffer goes
+ * straight into blurrily_storage_find_batch_device.  d_non_ascii[i] (optional)
+ * is set to 1 for a needle holding a byte >= 0x80: its NFKD decomposition is host
+ * work (the reference uses ActiveSupport's tables) and the caller must normalise
+ * that needle itself.  Asynchronous on `stream`.  0, or -1 with errno. */
+int blurrily_normalize_batch_device(const char* d_packed, const uint64_t* d_offsets, size_t n,
+                                    char* d_out, uint32_t* d_non_ascii, void* stream);
+
+/* blurrily_storage_find_batch over un-normalised ASCII needles: normalised on the
+ * device, then found.  non_ascii (optional, n slots) as above; rows of a flagged
+ * needle are those of its bytes >= 0x80 read as non-letters. */
+int blurrily_storage_find_batch_raw(trigram_map haystack, const char* packed, const uint64_t* offsets,
+                                    size_t n, uint16_t limit, trigram_match results, uint32_t* counts,
+                                    uint32_t* non_ascii);
+
 /* Build / refresh the device-resident index now (it is otherwise built lazily
  * by the first find after a mutation).  0, or -1 with errno. */
 int blurrily_storage_sync_device(trigram_map haystack);

@@ -16,10 +16,11 @@ def pytest_configure(config):
 def _gpu_available():
     try:
         import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
+        from blurrily_amd import _native
+        hip = _native.hip_runtime()                 # the one runtime of this process (see _native.py)
         n = ctypes.c_int(0)
         return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
-    except OSError:
+    except (OSError, ImportError):
         return False
 
 

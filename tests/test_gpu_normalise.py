@@ -1,0 +1,137 @@
+"""GPU parity of the device-side needle normaliser against the host mirror of
+Blurrily::Map#normalize_string (lib/blurrily/map.rb:40-47; pinned on the CPU side by
+tests/test_normalize.py against spec/blurrily/map_spec.rb's vectors)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import workloads as W
+from blurrily_amd import Map, RawMap, _native, normalize_string
+from blurrily_amd.map import _pack
+
+pytestmark = pytest.mark.gpu
+
+ALPHABET = (list(b"abcdefghijklmnopqrstuvwxyz") * 6 + list(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ") * 2 + list(b"      ")
+            + list(b"0123456789-_'.,;:!?@#()[]/\\\"") + [9, 10, 10, 11, 12, 13, 0, 127, 1, 31])
+
+
+def _seen_by_c(b):
+    """What the C side reads of a needle: the bytes up to the first NUL."""
+    return b.split(b"\0", 1)[0]
+
+
+def _random_ascii(rng, n):
+    out = []
+    for _ in range(n):
+        ln = int(rng.integers(0, 40))
+        out.append(bytes(rng.choice(ALPHABET, size=ln).tolist()))
+    return out
+
+
+class _Hip:
+    """Device buffers through the HIP runtime the library is bound to (no torch needed here)."""
+
+    def __init__(self):
+        self.rt = _native.hip_runtime()
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+
+    def to_device(self, arr):
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), max(arr.nbytes, 16)) == 0
+        assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+        return p
+
+    def to_host(self, p, like):
+        out = np.empty_like(like)
+        assert self.rt.hipMemcpy(out.ctypes.data, p, out.nbytes, 2) == 0      # synchronises the null stream
+        return out
+
+    def free(self, *ps):
+        for p in ps:
+            self.rt.hipFree(p)
+
+
+def _device_normalise(needles):
+    lib = _native.lib()
+    hip = _Hip()
+    packed, off = _pack(needles)
+    buf = np.frombuffer(packed, dtype=np.uint8) if len(packed) else np.zeros(0, dtype=np.uint8)
+    h_in = np.concatenate([buf, np.zeros(16, dtype=np.uint8)])
+    h_flags = np.zeros(len(needles), dtype=np.uint32)
+    d_in, d_off = hip.to_device(h_in), hip.to_device(off)
+    d_out, d_flags = hip.to_device(np.full_like(h_in, 0x55)), hip.to_device(h_flags)
+    assert lib.blurrily_normalize_batch_device(d_in, d_off, len(needles), d_out, d_flags, None) == 0, C.get_errno()
+    out, flags = hip.to_host(d_out, h_in).tobytes(), hip.to_host(d_flags, h_flags)
+    # in place as well, flags not asked for
+    assert lib.blurrily_normalize_batch_device(d_in, d_off, len(needles), d_in, None, None) == 0
+    inplace = hip.to_host(d_in, h_in).tobytes()
+    hip.free(d_in, d_off, d_out, d_flags)
+    got, got_inplace = [], []
+    for i in range(len(needles)):
+        a, b = int(off[i]), int(off[i + 1])
+        got.append(_seen_by_c(out[a:b]))
+        got_inplace.append(_seen_by_c(inplace[a:b]))
+    return got, got_inplace, flags
+
+
+def test_spec_vectors_and_edges():
+    needles = [b"London", b"  New   York ", b"Port-au-Prince", b"", b"   ", b"\t\n", b"A", b"@#%", b"abc\ndef",
+               b"abc\n@@ x", b"ab\ncd\0ef", b"\0abc", b"abc\0\0", b"Abc \0", b"x\ry", b"UPPER lower  MiXeD",
+               b"tab\tsep", b"trailing  ", b"  leading", b"a--b", b"ab\n", b"\nab", b"a\x7fb", b"plain line\nJUNK!!\n"]
+    got, got_inplace, flags = _device_normalise(needles)
+    for nd, g, gi in zip(needles, got, got_inplace):
+        want = _seen_by_c(normalize_string(nd.decode("latin1")).encode("latin1"))
+        assert g == want, (nd, g, want)
+        assert gi == want, (nd, gi, want)
+    assert not flags.any()
+
+
+def test_random_ascii_needles_match_the_host_mirror():
+    rng = np.random.default_rng(77)
+    needles = _random_ascii(rng, 20000)
+    got, got_inplace, flags = _device_normalise(needles)
+    want = [_seen_by_c(normalize_string(nd.decode("latin1")).encode("latin1")) for nd in needles]
+    assert got == want
+    assert got_inplace == want
+    assert not flags.any()
+
+
+def test_non_ascii_needles_are_flagged_not_guessed():
+    needles = ["café".encode(), b"plain", "@€%é".encode(), b"\x80", b"ok too"]
+    _, _, flags = _device_normalise(needles)
+    assert flags.tolist() == [1, 0, 1, 1, 0]
+
+
+def test_find_batch_raw_equals_find_over_host_normalised_needles():
+    rng = np.random.default_rng(5)
+    hay, off = W.geonames(60000, 8000, seed=17)
+    strings = W.unpack(hay, off)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, len(strings) + 1, dtype=np.uint32))
+    raw = []
+    for s in strings[:3000]:
+        t = bytearray(s.upper() if rng.random() < 0.3 else s)
+        for _ in range(int(rng.integers(0, 3))):
+            t.insert(int(rng.integers(0, len(t) + 1)), int(rng.choice(list(b" -_.,'\t"))))
+        raw.append(bytes(t))
+    raw += [b"", b"  ", b"!!!", b"Two\nLines"]
+    packed, offsets = _pack(raw)
+    rows_raw, counts_raw, flags = m.find_batch_raw_packed(packed, offsets, 10)
+    host = [normalize_string(r.decode("latin1")).encode("latin1") for r in raw]
+    hp, ho = _pack(host)
+    rows, counts = m.find_batch_packed(hp, ho, 10)
+    assert not flags.any()
+    assert np.array_equal(counts_raw, counts)
+    for i in range(len(raw)):
+        assert np.array_equal(rows_raw[i, :counts[i]], rows[i, :counts[i]]), raw[i]
+
+
+def test_map_find_batch_mixes_device_and_host_normalisation():
+    m = Map()
+    for i, s in enumerate(["london", "paris", "sao paulo", "cafe de flore", "new york"], start=1):
+        m.put(s, i)
+    needles = ["LONDON", "São  Paulo", "café de Flore", "New-York", "@€%é"]
+    assert m.find_batch(needles, 3) == [m.find(s, 3) for s in needles]
