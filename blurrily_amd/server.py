@@ -1,0 +1,183 @@
+"""Blurrily::Server (lib/blurrily/server.rb:7-48) as a batching front-end.
+
+Same wire protocol -- one tab-separated command per line, one reply line per command, replies in
+request order per connection -- and same life cycle (save every 60 s, on USR1 and on shutdown; INT
+and TERM stop it).  What differs is how FINDs reach the index: the reference runs one
+`Map#find` per line inside the reactor callback (server.rb:40-46); here the FINDs that arrive
+while the previous batch is on the GPU are coalesced into ONE `find_batch` per map, so throughput
+follows the GPU's batch rate instead of a per-call latency.  Ordering is kept: a PUT / DELETE /
+CLEAR on a map first flushes the FINDs queued before it on that map.
+"""
+import argparse
+import asyncio
+import os
+import signal
+from concurrent.futures import ThreadPoolExecutor
+
+from .command_processor import (COMMANDS, CommandProcessor, Find, ProtocolError, reply_error, reply_ok, reply_rows,
+                                split_fields)
+from .defaults import DEFAULT_PORT
+from .map_group import MapGroup
+
+
+class Server:
+    def __init__(self, host="0.0.0.0", port=DEFAULT_PORT, directory=None, max_batch=8192, coalesce=True,
+                 save_interval=60.0):
+        self._host, self._port = host, port                          # server.rb:10-12
+        self._map_group = MapGroup(directory or os.getcwd())
+        self._processor = CommandProcessor(self._map_group)
+        self._max_batch = max_batch if coalesce else 1
+        self._save_interval = save_interval
+        self._pending = []                                           # (line, future) in arrival order
+        self._wake = None
+        self._gpu = ThreadPoolExecutor(max_workers=1)                # one batch at a time, off the reactor
+        self._server = None
+        self._stopping = None
+        self.stats = {"finds": 0, "batches": 0, "largest_batch": 0, "commands": 0}
+
+    # ---- life cycle --------------------------------------------------------------------------
+    def start(self):                                                 # server.rb:18-31
+        asyncio.run(self.serve())
+
+    async def serve(self, ready=None):
+        loop = asyncio.get_running_loop()
+        self._wake = asyncio.Event()
+        self._stopping = asyncio.Event()
+        for sig in (signal.SIGINT, signal.SIGTERM):
+            loop.add_signal_handler(sig, self._stopping.set)
+        loop.add_signal_handler(signal.SIGUSR1, self._map_group.save)
+        self._server = await asyncio.start_server(self._handle, self._host, self._port)
+        self.port = self._server.sockets[0].getsockname()[1]
+        dispatcher = asyncio.ensure_future(self._dispatch())
+        saver = asyncio.ensure_future(self._periodic_save())
+        if ready is not None:
+            ready.set()
+        try:
+            await self._stopping.wait()
+        finally:
+            self._server.close()
+            await self._server.wait_closed()
+            saver.cancel()
+            dispatcher.cancel()
+            self._map_group.save()                                   # shutdown hook (server.rb:25)
+            self._gpu.shutdown(wait=True)
+
+    def stop(self):
+        if self._stopping is not None:
+            self._stopping.set()
+
+    async def _periodic_save(self):                                  # server.rb:23-24
+        while True:
+            await asyncio.sleep(self._save_interval)
+            self._map_group.save()
+
+    # ---- one connection ------------------------------------------------------------------------
+    async def _handle(self, reader, writer):
+        replies = asyncio.Queue()
+
+        async def write_in_order():
+            while True:
+                fut = await replies.get()
+                if fut is None:
+                    break
+                writer.write((await fut).encode("utf-8", "replace") + b"\n")
+                if replies.empty():
+                    await writer.drain()
+
+        sender = asyncio.ensure_future(write_in_order())
+        loop = asyncio.get_running_loop()
+        try:
+            while True:
+                raw = await reader.readline()
+                if not raw:
+                    break
+                line = raw.decode("utf-8", "replace").strip()        # server.rb:41-42
+                if not line and not raw.strip(b"\n"):
+                    continue                                         # split("\n") yields nothing for a blank line
+                fut = loop.create_future()
+                replies.put_nowait(fut)
+                self._pending.append((line, fut))
+                self._wake.set()
+        except (ConnectionError, asyncio.IncompleteReadError):
+            pass
+        finally:
+            replies.put_nowait(None)
+            try:
+                await sender
+                writer.close()
+            except (ConnectionError, asyncio.CancelledError):
+                pass
+
+    # ---- the dispatcher: arrival order in, batches out -------------------------------------------
+    async def _dispatch(self):
+        loop = asyncio.get_running_loop()
+        while True:
+            await self._wake.wait()
+            self._wake.clear()
+            while self._pending:
+                work, self._pending = self._pending[:self._max_batch], self._pending[self._max_batch:]
+                # everything that touches a map runs on the one worker thread, in arrival order
+                results = await loop.run_in_executor(self._gpu, self._run, [line for line, _ in work])
+                for (_, fut), reply in zip(work, results):
+                    if not fut.done():
+                        fut.set_result(reply)
+
+    def _run(self, lines):
+        """Replies for `lines`, in order.  Consecutive FINDs on one map become one batch; a mutation
+        of a map flushes that map's queued FINDs first."""
+        replies = [None] * len(lines)
+        queued = {}                                                  # map name -> [(index, Find)]
+
+        def flush(name):
+            batch = queued.pop(name, None)
+            if not batch:
+                return
+            try:
+                m = self._map_group.map(name)
+                limit = max(f.limit for _, f in batch)               # a smaller limit is a prefix of a larger one
+                rows = m.find_batch([f.needle for _, f in batch], limit)
+                for (i, f), r in zip(batch, rows):
+                    replies[i] = reply_rows(r[:f.limit])
+            except Exception as e:                                   # keep serving (the reference would die here)
+                for i, _ in batch:
+                    replies[i] = reply_error(str(e))
+            self.stats["finds"] += len(batch)
+            self.stats["batches"] += 1
+            self.stats["largest_batch"] = max(self.stats["largest_batch"], len(batch))
+
+        for i, line in enumerate(lines):
+            self.stats["commands"] += 1
+            fields = split_fields(line)
+            command = fields[0] if fields else None
+            name = fields[1] if len(fields) > 1 else None
+            try:
+                if command in COMMANDS and command != "FIND" and name is not None:
+                    flush(name)
+                parsed = self._processor.parse(line)
+                if isinstance(parsed, Find):
+                    queued.setdefault(parsed.map_name, []).append((i, parsed))
+                    if self._max_batch == 1:
+                        flush(parsed.map_name)
+                else:
+                    replies[i] = reply_ok(parsed)
+            except ProtocolError as e:
+                replies[i] = reply_error(str(e))
+            except Exception as e:
+                replies[i] = reply_error(str(e))
+        for name in list(queued):
+            flush(name)
+        return replies
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="blurrily front-end: tab-separated FIND/PUT/DELETE/CLEAR over TCP")
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=DEFAULT_PORT)
+    ap.add_argument("--directory", default=os.getcwd())
+    ap.add_argument("--no-coalesce", action="store_true", help="one find per FIND line, as the reference does")
+    args = ap.parse_args(argv)
+    Server(args.host, args.port, args.directory, coalesce=not args.no_coalesce).start()
+
+
+if __name__ == "__main__":
+    main()
