@@ -40,7 +40,7 @@
 namespace blurrily {
 
 #ifndef BLURRILY_WINDOW_BITS
-#define BLURRILY_WINDOW_BITS 16          // experiments: 15 halves the counters (4 workgroups of 512 per CU)
+#define BLURRILY_WINDOW_BITS 16          // (15 -- half the counters, 4 workgroups of 512 per CU -- was measured slower; find_kernels.hip now assumes 16)
 #endif
 constexpr uint32_t kWindowBits  = BLURRILY_WINDOW_BITS;
 constexpr uint32_t kWindowSize  = 1u << kWindowBits;    // counter slots per window (LDS)

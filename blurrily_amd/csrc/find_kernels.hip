@@ -325,6 +325,7 @@ __device__ __forceinline__ uint32_t hi_half_shl(uint32_t v) {
 // both ranks of a dword
 template <uint32_t ONE>
 __device__ __forceinline__ void bump_pair_bytes(uint32_t* cnt32, uint32_t v) {
+  static_assert(kWindowBits == 16, "the packed-dword arithmetic below is written for 16-bit in-window ranks");
   __hip_atomic_fetch_add(&cnt32[(v & 0xFFFFu) >> 2], ONE << ((v << 3) & 24u), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
   __hip_atomic_fetch_add(&cnt32[v >> 18], ONE << (hi_half_shl<3>(v) & 24u), __ATOMIC_RELAXED,
