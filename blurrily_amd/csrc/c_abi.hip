@@ -230,8 +230,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // swept by different workgroups, then merges the per-range candidates (single pass only).
     const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
     uint32_t ranges = 1;
-    if (limit <= 1024 && n < wgs / 2 && ix.n_windows > 1) {
-      ranges = uint32_t(std::min<size_t>(ix.n_windows, (2 * wgs) / n));
+    // Tasks aimed at: two per workgroup for a handful of needles, four from a hundred needles on
+    // (measured, tools/batch_sweep.py); from about one needle per workgroup whole needles win.
+    const size_t target_tasks = (n <= 96 ? 2 : 4) * wgs;
+    if (limit <= 1024 && target_tasks / n >= 4 && ix.n_windows > 2) {
+      ranges = uint32_t(std::min<size_t>((ix.n_windows + 1) / 2, target_tasks / n));   // ranges are whole window pairs
       ranges = std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit));     // merge pool
     }
     if (ranges > 1) {

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #endif
 #ifndef BLURRILY_NIBBLE
 #define BLURRILY_NIBBLE 1              // needles with <= 15 trigrams count in 4 bits, two windows per step
+#endif
+#ifndef BLURRILY_COOP_RANGED
+#define BLURRILY_COOP_RANGED 1         // latency mode sweeps its ranges with sweep_coop as well
 #endif
 #ifndef BLURRILY_COOP_ROTATE
 #define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
@@ -1021,8 +1025,10 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     const uint32_t R = RANGED ? A.ranges : 1u;
     const uint32_t item = RANGED ? slot / R : slot, range = RANGED ? slot - item * R : 0u;
     const uint32_t q = A.work_list ? A.work_list[item] : item;
-    const uint32_t w0 = RANGED ? uint32_t(uint64_t(A.n_windows) * range / R) : 0u;
-    const uint32_t w1 = RANGED ? uint32_t(uint64_t(A.n_windows) * (range + 1) / R) : A.n_windows;
+    // (ranges start on even windows: the 4-bit sweep takes windows in pairs)
+    const uint32_t n_pairs = (A.n_windows + 1) / 2;
+    const uint32_t w0 = RANGED ? 2 * uint32_t(uint64_t(n_pairs) * range / R) : 0u;
+    const uint32_t w1 = RANGED ? min(A.n_windows, 2 * uint32_t(uint64_t(n_pairs) * (range + 1) / R)) : A.n_windows;
     Needle nd;
     nd.T = A.q_ntri[q];
     if (!A.work_list && nd.T > (SHORT ? 64u : 127u)) { // longer needles: the mid / wide-counter launches
@@ -1054,7 +1060,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
-    if constexpr (SHORT && !RANGED && BLURRILY_COOP) {                                                  \
+    if constexpr (SHORT && (!RANGED || BLURRILY_COOP_RANGED) && BLURRILY_COOP) {                                                  \
       if (BLURRILY_NIBBLE && nd.T <= 15)  /* 4-bit counters: two windows per step */                    \
         sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
       else                                                                                              \
@@ -1277,16 +1283,22 @@ uint32_t find_pool_cap(uint32_t keep) {
   return cap;
 }
 
+// A kernel's dynamic-LDS ceiling is set once per device (a process may hold maps on several).
+static bool first_launch_on_this_device(std::atomic<uint64_t>& seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const uint64_t bit = 1ull << dev;
+  return (seen.fetch_or(bit) & bit) == 0;
+}
+
 template <typename CT, int NT, bool RANGED, bool SHORT>
 static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   const size_t lds = find_dynamic_lds_bytes(a.pool_cap);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done))
     BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024 - int(kWindowSize * sizeof(CT))));   // static counters
-    attr_done = true;
-  }
   hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
@@ -1313,12 +1325,10 @@ int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) 
   }
   constexpr int NT = 1024;                                    // keep <= 1024 keys per range
   const size_t lds = size_t(a.pool_cap) * 8 + sizeof(Control) + 16;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done))
     BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_parts_kernel<NT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
   hipLaunchKernelGGL((merge_parts_kernel<NT>), dim3(n_items), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;

@@ -293,3 +293,35 @@ def test_dense_and_empty_windows_mixed():
     needles = [b"london", b"londno", b"lon", b"zzzzqqqq", b"zq", b"don"] + W.unpack(hay, off)[:200]
     for limit in (1, 10, 300):
         _check_batch(m, o, needles, limit)
+
+
+def test_every_batch_size_regime_on_a_many_window_haystack():
+    """Eleven windows: a handful of needles is cut into window-pair ranges over many workgroups
+    (latency mode, byte and 4-bit counters alike), a few hundred into fewer ranges, a thousand
+    run whole -- the same needles must give the same rows in every regime."""
+    hay, off = W.geonames(700000, 60000, seed=31)
+    n = len(off) - 1
+    m, o = RawMap(), Oracle()
+    refs = np.arange(1, n + 1, dtype=np.uint32)
+    m.put_many_packed(hay, off, refs)
+    o.put_many(hay, off, refs)
+    q, qo = W.queries(hay, off, 1100, seed=12)
+    needles = W.unpack(q, qo)
+    assert m.device_info()["n_windows"] is not None
+    packed = b"".join(needles)
+    offs = np.zeros(len(needles) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in needles])
+    whole_rows, whole_counts = m.find_batch_packed(packed, offs, 10)          # 1100 needles: whole needles
+    assert m.device_info()["n_windows"] == 11
+    for i in range(0, 300):                                                     # the oracle on a sample
+        assert whole_rows[i, :whole_counts[i]].tolist() == o.find(needles[i], 10), needles[i]
+    for size in (1, 2, 7, 40, 97, 130, 300, 512, 600):
+        sub = needles[:size]
+        p = b"".join(sub)
+        so = np.zeros(size + 1, dtype=np.uint64)
+        so[1:] = np.cumsum([len(x) for x in sub])
+        rows, counts = m.find_batch_packed(p, so, 10)
+        assert np.array_equal(counts, whole_counts[:size]), size
+        assert np.array_equal(rows, whole_rows[:size]), size
+    _check_batch(m, o, needles[:60], 100)
+    _check_batch(m, o, needles[:5], 1000)
