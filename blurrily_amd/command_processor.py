@@ -78,10 +78,11 @@ class CommandProcessor:
             return reply_error(str(e))
 
     # ---- validation + the commands that do not touch the GPU --------------------------------
-    def parse(self, line):
+    def parse(self, line, fields=None):
         """Validate one line.  PUT / DELETE / CLEAR are executed here (returns None, i.e. a bare
         OK); a FIND comes back as a `Find` for the caller to run.  Raises ProtocolError."""
-        fields = split_fields(line)
+        if fields is None:
+            fields = split_fields(line)
         command = fields[0] if fields else None
         map_name = fields[1] if len(fields) > 1 else None
         args = fields[2:]

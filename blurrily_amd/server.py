@@ -73,6 +73,8 @@ class Server:
 
     # ---- one connection ------------------------------------------------------------------------
     async def _handle(self, reader, writer):
+        """Lines in, reply lines out, in order.  Whatever arrived in one read is queued as one item
+        (a pipelining client costs one future per read, not one per line)."""
         replies = asyncio.Queue()
 
         async def write_in_order():
@@ -80,23 +82,27 @@ class Server:
                 fut = await replies.get()
                 if fut is None:
                     break
-                writer.write((await fut).encode("utf-8", "replace") + b"\n")
+                out = await fut
+                writer.write(("\n".join(out) + "\n").encode("utf-8", "replace"))
                 if replies.empty():
                     await writer.drain()
 
         sender = asyncio.ensure_future(write_in_order())
         loop = asyncio.get_running_loop()
+        tail = b""
         try:
             while True:
-                raw = await reader.readline()
-                if not raw:
+                data = await reader.read(1 << 16)
+                if not data:
                     break
-                line = raw.decode("utf-8", "replace").strip()        # server.rb:41-42
-                if not line and not raw.strip(b"\n"):
-                    continue                                         # split("\n") yields nothing for a blank line
+                *complete, tail = (tail + data).split(b"\n")
+                # server.rb:41-42: data.split("\n") -- a blank line yields no command -- then strip
+                lines = [ln.decode("utf-8", "replace").strip() for ln in complete if ln]
+                if not lines:
+                    continue
                 fut = loop.create_future()
                 replies.put_nowait(fut)
-                self._pending.append((line, fut))
+                self._pending.append((lines, fut))
                 self._wake.set()
         except (ConnectionError, asyncio.IncompleteReadError):
             pass
@@ -115,12 +121,19 @@ class Server:
             await self._wake.wait()
             self._wake.clear()
             while self._pending:
-                work, self._pending = self._pending[:self._max_batch], self._pending[self._max_batch:]
+                work, n = [], 0
+                while self._pending and (not work or n + len(self._pending[0][0]) <= self._max_batch):
+                    item = self._pending.pop(0)
+                    work.append(item)
+                    n += len(item[0])
                 # everything that touches a map runs on the one worker thread, in arrival order
-                results = await loop.run_in_executor(self._gpu, self._run, [line for line, _ in work])
-                for (_, fut), reply in zip(work, results):
+                lines = [line for chunk, _ in work for line in chunk]
+                results = await loop.run_in_executor(self._gpu, self._run, lines)
+                at = 0
+                for chunk, fut in work:
                     if not fut.done():
-                        fut.set_result(reply)
+                        fut.set_result(results[at:at + len(chunk)])
+                    at += len(chunk)
 
     def _run(self, lines):
         """Replies for `lines`, in order.  Consecutive FINDs on one map become one batch; a mutation
@@ -153,7 +166,7 @@ class Server:
             try:
                 if command in COMMANDS and command != "FIND" and name is not None:
                     flush(name)
-                parsed = self._processor.parse(line)
+                parsed = self._processor.parse(line, fields)
                 if isinstance(parsed, Find):
                     queued.setdefault(parsed.map_name, []).append((i, parsed))
                     if self._max_batch == 1:
