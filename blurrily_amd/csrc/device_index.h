@@ -52,6 +52,8 @@ struct DeviceIndex {
   int       device        = -1;
   uint32_t  n_refs        = 0;
   uint32_t  n_windows     = 0;
+  uint32_t  nib_windows   = 0;             // windows [0, nib_windows) (an even count) hold no reference with more than
+                                         // 15 distinct trigrams: ANY needle can count them in 4 bits
   uint64_t  n_entries     = 0;        // real postings (padding excluded)
   uint64_t  n_slots       = 0;        // entries of `ent` including slice padding
   uint64_t  device_bytes  = 0;

@@ -308,6 +308,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   DeviceIndex ix;
   ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz; ix.n_slots = n_slots;
   ix.built_from = host.generation();
+  while (ix.nib_windows + 1 < n_win && win_max_tri[ix.nib_windows] <= 15 && win_max_tri[ix.nib_windows + 1] <= 15)
+    ix.nib_windows += 2;
   auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {   // v may be a temporary
     using T = typename std::remove_reference<decltype(v)>::type::value_type;
     const size_t bytes = std::max(v.size(), min_elems) * sizeof(T);

@@ -41,6 +41,7 @@ struct FindArgs {
   const uint32_t* q_nb;
   const uint32_t* q_start;     // [n] window the sweep starts at (the needle's own length class)
   const uint32_t* win_max_tri; // [n_windows] match-count bound per window
+  uint32_t        nib_windows; // windows [0, nib_windows): no reference with more than 15 trigrams (4-bit counters suffice)
   const uint32_t* tomb;        // bit r set: rank r was deleted after the image was built (nullptr: none)
   const uint32_t* work_list;   // nullptr: slots are needle ids, long needles skipped
   const uint32_t* n_work_dev;  // when set, the number of slots is read from the device

@@ -59,6 +59,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_COOP_RANGED
 #define BLURRILY_COOP_RANGED 1         // latency mode sweeps its ranges with sweep_coop as well
 #endif
+#ifndef BLURRILY_NIB_PREFIX
+#define BLURRILY_NIB_PREFIX 1          // needles with > 15 trigrams also count the short-reference windows in 4 bits
+#endif
 #ifndef BLURRILY_COOP_ROTATE
 #define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
 #endif
@@ -245,6 +248,7 @@ template <> struct Packing<Nib> {
 template <typename CT> struct ScanTraits {
   using P = Packing<CT>;
   static constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
+  static constexpr uint32_t kMaxCount = P::kTop - 1;
   struct Need { uint32_t bias; };
   static __device__ __forceinline__ Need prepare(uint32_t need) { return Need{(P::kTop - need) * P::kOnes}; }
   static __device__ __forceinline__ uint32_t hits(uint32_t v, Need n) { return (v + n.bias) & P::kHi; }
@@ -265,6 +269,7 @@ template <typename CT> struct ScanTraits {
 template <> struct ScanTraits<Nib> {
   using P = Packing<Nib>;
   static constexpr uint32_t kVecs = kWindowSize / 16;               // the same 64 KiB
+  static constexpr uint32_t kMaxCount = 15;
   // counter >= need, with c = counter, lo = c & 7:  need <= 8: c >= 8 or lo + (8 - need) >= 8;
   //                                                 need >  8: c >= 8 and lo + (16 - need) >= 8
   struct Need { uint32_t bias; bool low; };
@@ -441,7 +446,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
   const uint32_t tid = threadIdx.x;
   const uint32_t need = max(matches_needed(thr, nd.T, wbase), need_floor);
   const uint32_t nvec = S::nvec(wlen);
-  if (need <= nd.T) {
+  if (need <= min(nd.T, S::kMaxCount)) {                 // (a 4-bit window holds no counter above 15)
     const typename S::Need nq = S::prepare(need);
     // slow path of one vector: some counter reached `need`
     auto harvest = [&](const uint4 v, const uint32_t i) {
@@ -501,7 +506,7 @@ __device__ __forceinline__ uint32_t cold_start_need(const uint4* cnt128, uint32_
   using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t nvec = S::nvec(wlen);
-  uint32_t lo = 1, hi = T;                               // answer in [lo, hi]; lo = 1 means "no restriction"
+  uint32_t lo = 1, hi = min(T, S::kMaxCount);            // answer in [lo, hi]; lo = 1 means "no restriction"
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (tid == 0) ctl->tally = 0;
@@ -823,18 +828,16 @@ template <typename CT, int NT>
 __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
                            unsigned long long* pool, Control* ctl, UnitRing* ring, const uint32_t w0,
                            const uint32_t w1, const uint32_t ws) {
-  // A step covers kWPS windows: one with byte counters, two with 4-bit counters (CT = Nib,
-  // needles with <= 15 trigrams; lane l of the table then holds trigram l & 15 of window
-  // 2 * step + (l >> 4), and a unit's descriptor carries that parity in bit 0).
+  // A step covers kWPS windows: one with byte counters, two with 4-bit counters (CT = Nib).  Lane
+  // t of the table holds trigram t's slice of the step's window -- of both windows with 4-bit
+  // counters (second slot) -- and a unit's descriptor carries its window's parity in bit 0.
   constexpr bool kNib = std::is_same<CT, Nib>::value;
   constexpr uint32_t kWPS = kNib ? 2 : 1;
   constexpr uint32_t kNW = NT / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t tc = nd.T;                                     // <= 64 (<= 15 with 4-bit counters)
-  const uint32_t my_tri = kNib ? (lane & 15u) : lane;           // the slice this lane holds in the table ...
-  const uint32_t my_half = kNib ? (lane >> 4) : 0u;             // ... and the window of the step it belongs to
-  const bool own = my_tri < tc && my_half < kWPS;
-  const uint32_t code = own ? codes[my_tri] : 0u;
+  const uint32_t tc = nd.T;                                     // <= 64
+  const bool own = lane < tc;
+  const uint32_t code = own ? codes[lane] : 0u;
   const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
   const uint32_t n_visit = v1 - v0;
 #define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
@@ -856,20 +859,26 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       ++out_;                                                                    \
     }                                                                            \
   } while (0)
-#define BLURRILY_FETCH_TABLE(p_, A0, B0)                                         \
+  // slice table of step p_: (A0, B0) the (even) window, (A1, B1) the odd one with 4-bit counters
+#define BLURRILY_FETCH_TABLE(p_, A0, B0, A1, B1)                                 \
   do {                                                                           \
-    A0 = B0 = 0;                                                                 \
-    const uint32_t w_ = (p_) * kWPS + my_half;                                   \
+    A0 = B0 = A1 = B1 = 0;                                                       \
+    const uint32_t w_ = (p_) * kWPS;                                             \
     if (w_ < w1 && own) {                                                        \
       const uint32_t idx_ = w_ * kNumCodes + code;                               \
       A0 = A.slice_off[idx_]; B0 = A.slice_off[idx_ + 1];                        \
     }                                                                            \
+    if (kNib && w_ + 1 < w1 && own) {                                            \
+      const uint32_t idx_ = (w_ + 1) * kNumCodes + code;                         \
+      A1 = A.slice_off[idx_]; B1 = A.slice_off[idx_ + 1];                        \
+    }                                                                            \
   } while (0)
-  // this wave publishes the units of the table (ta, tb) into ring slot s_
-#define BLURRILY_PRODUCE(s_, ta, tb)                                             \
+  // this wave publishes the units of the table into ring slot s_: a lane's even-window units,
+  // then its odd-window units
+#define BLURRILY_PRODUCE(s_, A0, B0, A1, B1)                                     \
   do {                                                                           \
-    const uint32_t units_ = slice_units(ta, tb);                                 \
-    uint32_t incl_ = units_;                                                     \
+    const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
+    uint32_t incl_ = units0_ + units1_;                                          \
     _Pragma("unroll") for (uint32_t d_ = 1; d_ < 64; d_ <<= 1) {                 \
       const uint32_t up_ = __shfl_up(incl_, d_);                                 \
       if (lane >= d_) incl_ += up_;                                              \
@@ -878,9 +887,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (total_ > kRingUnits) {                                                   \
       if (lane == 0) ring->n_units[s_] = kRingOverflow;                          \
     } else {                                                                     \
-      uint32_t at_ = incl_ - units_;                                             \
-      for (uint32_t j_ = 0; j_ < units_; ++j_, ++at_)                            \
-        ring->desc[s_][at_] = make_uint2((ta + j_ * 512) | my_half, tb);         \
+      uint32_t at_ = incl_ - units0_ - units1_;                                  \
+      for (uint32_t j_ = 0; j_ < units0_; ++j_, ++at_)                           \
+        ring->desc[s_][at_] = make_uint2(A0 + j_ * 512, B0);                     \
+      for (uint32_t j_ = 0; j_ < units1_; ++j_, ++at_)                           \
+        ring->desc[s_][at_] = make_uint2((A1 + j_ * 512) | 1u, B1);              \
       if (lane == 0) ring->n_units[s_] = total_;                                 \
     }                                                                            \
   } while (0)
@@ -909,10 +920,13 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // more units than the ring holds: every wave walks the table of step p_ itself
 #define BLURRILY_COUNT_WALK(p_)                                                  \
   do {                                                                           \
-    uint32_t fa_, fb_, k_ = 0;                                                   \
-    BLURRILY_FETCH_TABLE(p_, fa_, fb_);                                          \
-    BLURRILY_FOR_SLOT_UNITS(kNW, fa_, fb_, wid, lane, k_,                        \
-                            { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), kNib ? (t_ >> 4) : 0u); }); \
+    uint32_t fa0_, fb0_, fa1_, fb1_, k_ = 0;                                     \
+    BLURRILY_FETCH_TABLE(p_, fa0_, fb0_, fa1_, fb1_);                            \
+    BLURRILY_FOR_SLOT_UNITS(kNW, fa0_, fb0_, wid, lane, k_,                      \
+                            { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 0u); }); \
+    if (kNib)                                                                    \
+      BLURRILY_FOR_SLOT_UNITS(kNW, fa1_, fb1_, wid, lane, k_,                    \
+                              { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); }); \
   } while (0)
 #if BLURRILY_COOP_ROTATE
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
@@ -920,17 +934,17 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #define BLURRILY_PRODUCER(e_) (kNW - 1)                        /* units go round robin: the last wave has the fewest */
 #endif
 
-  uint32_t ta = 0, tb = 0;                                      // table this wave will publish next
+  uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
   uint32_t i_cur = 0, i_next, i_next2;
   // prologue: one wave publishes the first step, everyone agrees on the second
   if (wid == BLURRILY_PRODUCER(0u)) {
-    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb);
-    BLURRILY_PRODUCE(0u, ta, tb);
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
+    BLURRILY_PRODUCE(0u, ta, tb, ta1, tb1);
   }
   __syncthreads();
   BLURRILY_NEXT_VISIT(1u, i_next);
-  if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next), ta, tb);
+  if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next), ta, tb, ta1, tb1);
 
   for (uint32_t e = 0; i_cur < n_visit; ++e) {
     const uint32_t s = e & 1;
@@ -948,7 +962,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     PHASE_MARK(2);                                              // units counted
     // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
     if (wid == BLURRILY_PRODUCER(e + 1)) {
-      if (i_next < n_visit) BLURRILY_PRODUCE(s ^ 1u, ta, tb);
+      if (i_next < n_visit) BLURRILY_PRODUCE(s ^ 1u, ta, tb, ta1, tb1);
       else if (lane == 0) ring->n_units[s ^ 1u] = 0;
     }
     PHASE_MARK(7);                                              // (producer turn) next step's units published
@@ -956,7 +970,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     PHASE_MARK(3);                                              // barrier after count
     // ---- decide the step after the next; its table travels during the scan -------------------
     BLURRILY_NEXT_VISIT(i_next + 1, i_next2);                   // uniform: thr only changes behind select's barriers
-    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb);
+    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb, ta1, tb1);
     PHASE_MARK(4);                                              // step after the next chosen
     if (n_units) {
       for (;;) {
@@ -1060,18 +1074,25 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
-    if constexpr (SHORT && (!RANGED || BLURRILY_COOP_RANGED) && BLURRILY_COOP) {                                                  \
-      if (BLURRILY_NIBBLE && nd.T <= 15)  /* 4-bit counters: two windows per step */                    \
-        sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
-      else                                                                                              \
-        sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, a_, b_, start_); \
+    const uint32_t sa = (a_), sb = (b_), st = (start_);                                                 \
+    if constexpr (SHORT && (!RANGED || BLURRILY_COOP_RANGED) && BLURRILY_COOP) {                        \
+      /* 4-bit counters, two windows per step: every window for a needle with <= 15 trigrams, and for   \
+         ANY needle the leading windows whose references have <= 15 trigrams (ranks follow weight, i.e. \
+         length: about half the windows at Geonames scale) -- a counter there cannot exceed 15 whatever \
+         the needle.  The byte-counter part goes first: it holds the needle's own length class. */      \
+      const uint32_t nib_end = !BLURRILY_NIBBLE ? sa : nd.T <= 15 ? sb                                  \
+                               : BLURRILY_NIB_PREFIX ? min(sb, max(sa, A.nib_windows)) : sa;            \
+      if (nib_end < sb)                                                                                 \
+        sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, nib_end, sb, max(st, nib_end));        \
+      if (sa < nib_end)                                                                                 \
+        sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, sa, nib_end, min(st, nib_end - 1));   \
     } else if constexpr (SHORT) {                                                                       \
-      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
+      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);  \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
-      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_);                 \
+      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);                     \
     } else {                                                                                            \
-      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, a_, b_, start_); \
-      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, a_, b_);     \
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, sa, sb, st); \
+      else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, sa, sb);     \
     }                                                                                                   \
   } while (0)
     if constexpr (RANGED) {

@@ -325,3 +325,33 @@ def test_every_batch_size_regime_on_a_many_window_haystack():
         assert np.array_equal(rows, whole_rows[:size]), size
     _check_batch(m, o, needles[:60], 100)
     _check_batch(m, o, needles[:5], 1000)
+
+
+def test_long_needles_over_short_reference_windows():
+    """Needles with 16..64 distinct trigrams sweep the windows of short references (<= 15 trigrams
+    each) with 4-bit counters, two windows per step, and the rest with byte counters: both kinds in
+    one sweep, every trigram of the needle counted in both."""
+    rng = np.random.default_rng(41)
+    hay, off = W.geonames(400000, 40000, seed=29)            # 7 windows, the first ones all short strings
+    strings = W.unpack(hay, off)
+    n = len(strings)
+    m, o = RawMap(), Oracle()
+    refs = np.arange(1, n + 1, dtype=np.uint32)
+    m.put_many_packed(hay, off, refs)
+    o.put_many(hay, off, refs)
+    needles = []
+    for _ in range(150):                                       # several haystack strings glued together
+        k = int(rng.integers(2, 6))
+        needles.append(b" ".join(strings[int(i)] for i in rng.integers(0, n, size=k))[:int(rng.integers(16, 64))])
+    assert min(len(set(Oracle.tokenise(nd))) for nd in needles) >= 10
+    assert max(len(set(Oracle.tokenise(nd))) for nd in needles) > 40
+    _check_batch(m, o, needles, 10)                            # latency mode (ranges)
+    _check_batch(m, o, needles[:40], 120)
+    big = needles * 8                                          # 1200 needles: whole needles per workgroup
+    packed = b"".join(big)
+    offs = np.zeros(len(big) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in big])
+    rows, counts = m.find_batch_packed(packed, offs, 10)
+    for i, nd in enumerate(needles):
+        assert rows[i, :counts[i]].tolist() == o.find(nd, 10), nd
+        assert np.array_equal(rows[i], rows[i + len(needles)])
