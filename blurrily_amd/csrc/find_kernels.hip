@@ -62,6 +62,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_NIB_PREFIX
 #define BLURRILY_NIB_PREFIX 1          // needles with > 15 trigrams also count the short-reference windows in 4 bits
 #endif
+#ifndef BLURRILY_RANK_SORT_MAX
+#define BLURRILY_RANK_SORT_MAX 256     // pools up to this size are compacted by rank counting, larger ones by a bitonic sort
+#endif
 #ifndef BLURRILY_COOP_ROTATE
 #define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
 #endif
@@ -395,6 +398,25 @@ template <int NT>
 __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t cap, uint32_t keep) {
   const uint32_t tid = threadIdx.x;
   const uint32_t n = min(ctl->pool_n, cap);
+  if (BLURRILY_RANK_SORT_MAX && n <= BLURRILY_RANK_SORT_MAX) {
+    // Small pools (most of them): every key counts the keys below it -- the keys are distinct,
+    // a rank being harvested once -- and the best `keep` go straight to their places: three
+    // barriers instead of the bitonic network's dozens.
+    const unsigned long long mine = tid < n ? pool[tid] : kKeyInf;
+    uint32_t below = 0;
+    if (tid < n)
+      for (uint32_t j = 0; j < n; ++j) below += pool[j] < mine;     // same address in every lane: a broadcast
+    __syncthreads();
+    if (tid < n && below < keep) pool[below] = mine;
+    __syncthreads();
+    if (tid == 0) {
+      ctl->pool_n = min(n, keep);
+      ctl->overflow = 0;
+      if (n >= keep && keep > 0) ctl->thr = pool[keep - 1];
+    }
+    __syncthreads();
+    return;
+  }
   uint32_t P = 1;
   while (P < n) P <<= 1;
   for (uint32_t i = n + tid; i < P; i += NT) pool[i] = kKeyInf;
