@@ -77,6 +77,10 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifdef BLURRILY_PHASE_PROFILE
 #define PHASE_DECL unsigned long long ph_last = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_units = 0, ph_lanes = 0
 // head units of wave 0 and their live lanes (lane utilisation of the LDS atomics)
+// per needle, in the kernel body: slot 10 setup (queue pop .. first sweep), 11 the sweeps, 12 final compaction and rows
+#define PHASE_NEEDLE_DECL unsigned long long pn_last = clock64()
+#define PHASE_NEEDLE(i) do { const unsigned long long t_ = clock64(); if (threadIdx.x == 0 && A.phase_clocks) \
+    atomicAdd(&A.phase_clocks[blockIdx.x * 16 + (i)], t_ - pn_last); pn_last = t_; } while (0)
 #define PHASE_UNIT(v) do { const unsigned long long m_ = __ballot(group_live(v)); if (m_) { ++ph_units; ph_lanes += __popcll(m_); } } while (0)
 #define PHASE_MARK(i) do { const unsigned long long t_ = clock64(); ph_acc[i] += t_ - ph_last; ph_last = t_; } while (0)
 #define PHASE_FLUSH(A) do { if (threadIdx.x == 0 && (A).phase_clocks) { \
@@ -84,6 +88,8 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
     atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + 8], ph_units); atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + 9], ph_lanes); } } while (0)
 #else
 #define PHASE_DECL
+#define PHASE_NEEDLE_DECL
+#define PHASE_NEEDLE(i)
 #define PHASE_MARK(i)
 #define PHASE_UNIT(v)
 #define PHASE_FLUSH(A)
@@ -1051,6 +1057,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
   const uint32_t n_work = A.n_work_dev ? *A.n_work_dev : A.n_work;
 
+  PHASE_NEEDLE_DECL;
   for (;;) {
     if (tid == 0) ctl->q = atomicAdd(A.queue, 1u);
     __syncthreads();
@@ -1093,6 +1100,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     }
     __syncthreads();
 
+    PHASE_NEEDLE(10);
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
@@ -1131,6 +1139,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     }
     BLURRILY_SWEEP(w0, w1, ws);
 #undef BLURRILY_SWEEP
+    PHASE_NEEDLE(11);
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
     compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
@@ -1157,6 +1166,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
       if (A.floor && nres > 0) A.floor[q] = pool[nres - 1];
     }
     __syncthreads();                                   // pool reads done before the next needle resets it
+    PHASE_NEEDLE(12);
   }
 }
 

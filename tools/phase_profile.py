@@ -48,6 +48,8 @@ def main():
         for name, v in zip(PHASES, per_window):
             print(f"   {name:22s} {v:9.0f}")
         print(f"   {'TOTAL':22s} {per_window.sum():9.0f}")
+        per_needle = tot_all[10:13] / batch
+        print(f"   per needle: setup {per_needle[0]:9.0f}  sweeps {per_needle[1]:9.0f}  final compaction + rows {per_needle[2]:9.0f}")
         if tot_all[8]:
             print(f"   wave 0 head units per (query, window): {tot_all[8] / (batch * info['n_windows']):.2f}, "
                   f"live lanes per unit: {tot_all[9] / tot_all[8]:.1f} of 64")
