@@ -290,6 +290,10 @@ def main():
             "entries_per_query": sum_nb / n_q,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # the physical stream: PMC bytes per launch (a separate rocprofv3 --pmc run of this
+                         # workload, profiles/) over this run's kernel time, against the same peak
+                         "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024"),
                          "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
