@@ -162,8 +162,16 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   uint16_t last = 0;
   for (uint64_t k = 0; k < m; ++k) {
     const uint16_t v = work[k];
-    if (d == 0 || last != v) { out[d++] = v; last = v; nb += code_total[v]; }
+    if (d == 0 || last != v) { out[d++] = v; last = v; }
   }
+  // (bucket sizes in a loop of their own, four loads in flight: a single needle waits on nothing else)
+  uint32_t k4 = 0;
+  for (; k4 + 4 <= d; k4 += 4) {
+    const uint32_t c0 = code_total[out[k4]], c1 = code_total[out[k4 + 1]], c2 = code_total[out[k4 + 2]],
+                   c3 = code_total[out[k4 + 3]];
+    nb += uint64_t(c0) + c1 + c2 + c3;
+  }
+  for (; k4 < d; ++k4) nb += code_total[out[k4]];
   q_ntri[q] = d;
   q_start[q] = start_win[len < 255 ? len : 255];   // where references as long as the needle live
   q_nb[q] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
@@ -1129,7 +1137,8 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
       // A range that does not contain the needle's own length class first sweeps that window
       // only to learn a threshold (the keep-th best of real candidates bounds the answer), then
       // forgets those candidates -- the range that owns the window reports them -- and sweeps
-      // its own windows with few admissions instead of a cold start.
+      // its own windows with few admissions instead of a cold start.  (It pays even for a range
+      // of one step: without it a single needle takes 88 us instead of 81.)
       if (qs < A.n_windows && !(qs >= w0 && qs < w1)) {
         BLURRILY_SWEEP(qs, qs + 1, qs);
         compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
