@@ -190,7 +190,8 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
 
   if (m->timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev[0], stream));
   TokeniseArgs t{d_packed, d_offsets, uint32_t(n), d_code_total, static_cast<uint16_t*>(m->ws_codes.p),
-                 q_ntri, q_nb, big_list, scalars, mid_list, scalars + 1, ix.d_start_win, q_start};
+                 q_ntri, q_nb, big_list, scalars, mid_list, scalars + 1, ix.d_start_win, q_start,
+                 maybe_mid ? 0u : 63u};                  // host-buffer batches know their longest needle
   if (launch_tokenise(t, stream) < 0) return -1;
   if (m->timing) {
     BLURRILY_HIP_TRY(hipEventRecord(m->ev[1], stream));

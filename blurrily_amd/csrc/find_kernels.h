@@ -24,6 +24,7 @@ struct TokeniseArgs {
   uint32_t*       mid_count;   // [1]
   const uint32_t* start_win;   // [256] index table: first window of a weight
   uint32_t*       q_start;     // [n] window a needle's sweep starts at
+  uint32_t        max_len;     // longest needle in bytes if the host knows it, else 0
 };
 
 struct FindArgs {

@@ -179,6 +179,59 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, two table slots per lane
 }
 
+// The same, one WAVE per needle (needles of at most 63 bytes; small batches, where one lane per
+// needle leaves a single lane sorting and chasing bucket sizes alone): lane k encodes position k,
+// a bitonic network over the 64 lanes sorts, a ballot drops the duplicates, the bucket sizes are
+// loaded one per lane and summed across the wave.
+__global__ __launch_bounds__(64) void tokenise_wave_kernel(const char* __restrict__ packed,
+                                                           const uint64_t* __restrict__ offsets, uint32_t n,
+                                                           const uint32_t* __restrict__ code_total,
+                                                           uint16_t* __restrict__ qcodes, uint32_t* __restrict__ q_ntri,
+                                                           uint32_t* __restrict__ q_nb,
+                                                           const uint32_t* __restrict__ start_win,
+                                                           uint32_t* __restrict__ q_start) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  if (q >= n) return;
+  const uint64_t beg = offsets[q];
+  const uint32_t cap = uint32_t(offsets[q + 1] - beg);                   // <= 63 (the launcher checked)
+  const unsigned char ch = lane < cap ? static_cast<unsigned char>(packed[beg + lane]) : 0;
+  const unsigned long long nul = __ballot(lane < cap && ch == 0);
+  const uint32_t len = nul ? uint32_t(__builtin_ctzll(nul)) : cap;       // a needle is a C string (storage.c:480)
+  const uint32_t m = len + 1;                                            // positions of "**" + s + "*" (tokeniser.c:62-75)
+  const uint32_t c = lane < len ? dev_symbol(ch) : 0u;
+  const uint32_t b1 = __shfl_up(c, 1), a2 = __shfl_up(c, 2);
+  const uint32_t code = (lane >= 2 ? a2 : 0u) + 28u * (lane >= 1 ? b1 : 0u) + 784u * c;
+  uint32_t key = lane < m ? code : 0xFFFFu;                              // sentinel above every code
+  // bitonic sort, ascending over the lanes (tokeniser.c:93)
+#pragma unroll
+  for (uint32_t size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint32_t other = __shfl_xor(key, int(stride));
+      const bool up = (lane & size) == 0;                                // direction of this lane's block
+      const bool low = (lane & stride) == 0;                             // lower lane of the pair
+      key = (low == up) ? min(key, other) : max(key, other);
+    }
+  }
+  // drop duplicates (tokeniser.c:96-107), sum bucket sizes (storage.c:498-502)
+  const uint32_t prev = __shfl_up(key, 1);
+  const bool uniq = lane < m && (lane == 0 || key != prev);
+  const unsigned long long keep = __ballot(uniq);
+  uint16_t* out = qcodes + beg + q;
+  if (uniq) out[__popcll(keep & ((1ull << lane) - 1))] = uint16_t(key);
+  unsigned long long nb = uniq ? code_total[key] : 0u;
+#pragma unroll
+  for (int d = 32; d; d >>= 1) {
+    const uint32_t lo = __shfl_xor(uint32_t(nb), d), hi = __shfl_xor(uint32_t(nb >> 32), d);
+    nb += (static_cast<unsigned long long>(hi) << 32) | lo;
+  }
+  if (lane == 0) {
+    q_ntri[q] = uint32_t(__popcll(keep));
+    q_start[q] = start_win[len];                                         // len <= 63
+    q_nb[q] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
+  }
+}
+
 // ------------------------------------------------------------ normaliser ---
 // Blurrily::Map#normalize_string (lib/blurrily/map.rb:40-47) for ASCII needles, one lane per
 // needle, byte for byte what the Ruby does:
@@ -1320,6 +1373,12 @@ size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
 
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream) {
   if (t.n == 0) return 0;
+  if (t.n <= 16384 && t.max_len && t.max_len <= 63) {          // short needles, not a huge batch: a wave per needle
+    hipLaunchKernelGGL(tokenise_wave_kernel, dim3(t.n), dim3(64), 0, stream, t.packed, t.offsets, t.n, t.code_total,
+                       t.qcodes, t.q_ntri, t.q_nb, t.start_win, t.q_start);
+    BLURRILY_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const uint32_t block = 128;
   const uint32_t grid = (t.n + block - 1) / block;
   hipLaunchKernelGGL(tokenise_kernel, dim3(grid), dim3(block), 0, stream, t.packed, t.offsets, t.n,
