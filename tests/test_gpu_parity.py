@@ -355,3 +355,48 @@ def test_long_needles_over_short_reference_windows():
     for i, nd in enumerate(needles):
         assert rows[i, :counts[i]].tolist() == o.find(nd, 10), nd
         assert np.array_equal(rows[i], rows[i + len(needles)])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_configurations(seed):
+    """Seeded sweep over what a haystack and a batch can look like: size (one window to several), the
+    three generators, custom weights (ranks then do not follow length, so the 4-bit window prefix is
+    short or empty), sparse references, deletes before and after the first find, any limit, short
+    and long needles, a handful of needles (ranges) and a thousand (whole needles)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([900, 40000, 70000, 150000, 260000]))
+    gen = [lambda: W.geonames(n, max(500, n // 12), 50 + seed), lambda: W.words(n, 60 + seed),
+           lambda: W.skewed(n, 70 + seed)][seed % 3]
+    hay, off = gen()
+    strings = W.unpack(hay, off)
+    n = len(strings)
+    refs = (rng.choice(2**31 - 2, size=n, replace=False) + 1).astype(np.uint32) if seed % 2 else \
+        np.arange(1, n + 1, dtype=np.uint32)
+    weights = None
+    if seed % 4 >= 2:                                          # custom weights, zeros (-> strlen) mixed in
+        weights = rng.integers(0, 40, size=n).astype(np.uint32)
+        weights[rng.random(n) < 0.3] = 0
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(hay, off, refs, weights)
+    if weights is None:
+        o.put_many(hay, off, refs)
+    else:
+        for s, r, w in zip(strings, refs.tolist(), weights.tolist()):
+            o.put(s, r, w)
+    for r in rng.choice(refs, size=min(200, n // 4), replace=False).tolist():    # deletes before the first find
+        assert m.delete(r) == o.delete(r)
+    q, qo = W.queries(hay, off, 110, seed=80 + seed)
+    needles = W.unpack(q, qo) + [b"", b"q", strings[0] + b" " + strings[-1] + b" " + strings[n // 2]]
+    limit = int(rng.choice([1, 2, 10, 33, 100, 257]))
+    _check_batch(m, o, needles, limit)
+    for r in rng.choice(refs, size=min(50, n // 8), replace=False).tolist():     # and after (tombstones)
+        assert m.delete(r) == o.delete(r)
+    m.put(b"an entirely new entry", 2**31 - 1, 0); o.put(b"an entirely new entry", 2**31 - 1, 0)
+    _check_batch(m, o, needles[:20] + [b"an entirely new"], limit)
+    big = needles * 10                                         # > 1000 needles: whole needles per workgroup
+    packed = b"".join(big)
+    offs = np.zeros(len(big) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in big])
+    rows, counts = m.find_batch_packed(packed, offs, limit)
+    for i, nd in enumerate(needles):
+        assert rows[i, :counts[i]].tolist() == o.find(nd, limit), (nd, limit)
