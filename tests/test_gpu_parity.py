@@ -2,6 +2,8 @@
 
 Reads like spec/blurrily/map_spec.rb '#find' (:118-210) plus seeded random haystacks.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -357,7 +359,10 @@ def test_long_needles_over_short_reference_windows():
         assert np.array_equal(rows[i], rows[i + len(needles)])
 
 
-@pytest.mark.parametrize("seed", range(10))
+_FUZZ_FIRST = int(os.environ.get("BLURRILY_FUZZ_FIRST", "0"))           # soak runs: BLURRILY_FUZZ_FIRST=10 BLURRILY_FUZZ_SEEDS=50
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("BLURRILY_FUZZ_SEEDS", "10"))))
 def test_randomised_configurations(seed):
     """Seeded sweep over what a haystack and a batch can look like: size (one window to several), the
     three generators, custom weights (ranks then do not follow length, so the 4-bit window prefix is
