@@ -388,6 +388,14 @@ int blurrily_storage_put(trigram_map haystack, const char* needle, uint32_t refe
 
 long blurrily_storage_put_many(trigram_map haystack, const char* packed, const uint64_t* offsets,
                                const uint32_t* references, const uint32_t* weights, size_t n) {
+  // A bulk import -- no device image to keep in step, or more strings than the mutation log takes:
+  // the image is rebuilt at the next find anyway -- goes through the parallel host path.
+  const bool tracked = haystack->dev.device >= 0 && !haystack->log_overflow;
+  if (n >= 65536 && (!tracked || n > log_budget(haystack))) {
+    const long added = haystack->host->put_many(packed, offsets, references, weights, n);
+    if (tracked && added > 0) { haystack->pending.clear(); haystack->log_overflow = true; }
+    return added;
+  }
   long total = 0;
   for (size_t i = 0; i < n; ++i) {
     const char* s = packed + offsets[i];

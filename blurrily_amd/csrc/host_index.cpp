@@ -2,11 +2,14 @@
 #include "host_index.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cerrno>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -169,6 +172,131 @@ int HostIndex::put(const char* needle, size_t len, uint32_t ref, uint32_t weight
   ++generation_;
   if (codes != small) std::free(codes);
   return n;
+}
+
+long HostIndex::put_many(const char* packed, const uint64_t* offsets, const uint32_t* refs,
+                         const uint32_t* weights, size_t n) {
+  if (n == 0) return 0;
+  const bool trace = std::getenv("BLURRILY_BUILD_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "blurrily_hip: put_many: %-28s %8.1f ms\n", what,
+                 std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  ensure_refset();
+  // 1. which strings are stored: a reference already known -- or seen earlier in this batch -- is
+  //    skipped (storage.c:408); string order decides, so this pass is sequential
+  std::vector<uint8_t> take(n);
+  size_t accepted = 0;
+  for (size_t i = 0; i < n; ++i) {
+    take[i] = !refs_.test(refs[i]);
+    if (take[i]) { refs_.add(refs[i]); ++accepted; }
+  }
+  if (!accepted) return 0;
+  stage("reference set");
+
+  // 2. tokenise in parallel, chunk by chunk: codes of every stored string, and how many entries
+  //    each chunk adds to each bucket
+  const size_t n_chunks = std::max<size_t>(1, std::min<size_t>({size_t(std::thread::hardware_concurrency()), 64, n / 4096 + 1}));
+  const size_t per = (n + n_chunks - 1) / n_chunks;
+  struct Chunk { std::vector<uint16_t> codes; std::vector<uint32_t> ncodes, lens; std::vector<uint32_t> hist; long added = 0; };
+  std::vector<Chunk> chunks(n_chunks);
+  auto for_chunks = [&](auto&& body) {
+    std::vector<std::thread> th;
+    for (size_t c = 1; c < n_chunks; ++c) th.emplace_back([&, c] { body(c); });
+    body(0);
+    for (auto& t : th) t.join();
+  };
+  for_chunks([&](size_t c) {
+    const size_t lo = c * per, hi = std::min(n, lo + per);
+    const size_t cnt = hi > lo ? hi - lo : 0;
+    // (locals, handed over at the end: the chunks sit next to each other in memory)
+    std::vector<uint16_t> codes;
+    std::vector<uint32_t> ncodes(cnt, 0), lens(cnt, 0), hist(kNumCodes, 0);
+    codes.reserve(cnt * 16);
+    long added = 0;
+    uint16_t small[256];
+    std::vector<uint16_t> big;
+    for (size_t i = lo; i < hi; ++i) {
+      if (!take[i]) continue;
+      const char* s = packed + offsets[i];
+      const size_t cap = size_t(offsets[i + 1] - offsets[i]);
+      const void* nul = std::memchr(s, 0, cap);
+      const size_t len = nul ? size_t(static_cast<const char*>(nul) - s) : cap;
+      uint16_t* tmp = small;
+      if (len + 1 > 256) { big.resize(len + 1); tmp = big.data(); }
+      const int k = tokenise(s, len, tmp);
+      codes.insert(codes.end(), tmp, tmp + k);
+      ncodes[i - lo] = uint32_t(k);
+      lens[i - lo] = uint32_t(len);
+      for (int j = 0; j < k; ++j) ++hist[tmp[j]];
+      added += k;
+    }
+    Chunk& ck = chunks[c];
+    ck.codes.swap(codes); ck.ncodes.swap(ncodes); ck.lens.swap(lens); ck.hist.swap(hist); ck.added = added;
+  });
+  stage("tokenise");
+  // 3. per bucket: where each chunk writes (chunks in string order: the order of n puts), and the
+  //    array the reference's growth rule ends with (512 slots, then x 4/3 whenever full; a grown
+  //    array is the old one copied whole, the rest 0xAA -- storage.c:424-458)
+  std::vector<uint32_t> start(size_t(n_chunks) * kNumCodes);
+  {
+    std::vector<std::thread> th;
+    const uint32_t n_thr = uint32_t(std::max<size_t>(1, std::min<size_t>(n_chunks, 32)));
+    auto grow = [&](uint32_t t0, uint32_t t1) {
+      for (uint32_t t = t0; t < t1; ++t) {
+        Bucket& bk = b_[t];
+        uint32_t at = bk.used;
+        for (size_t c = 0; c < n_chunks; ++c) { start[c * kNumCodes + t] = at; at += chunks[c].hist[t]; }
+        if (at == bk.used) continue;
+        uint32_t slots = bk.slots ? bk.slots : kFirstSlots;
+        while (slots < at) {
+          uint32_t grown = uint32_t(uint64_t(slots) * 4 / 3);
+          if (grown <= slots) grown = slots + 1;
+          slots = grown;
+        }
+        if (slots != bk.slots) {
+          Entry* ne = alloc_slots(slots);
+          if (bk.slots) std::memcpy(ne, bk.e, size_t(bk.slots) * sizeof(Entry));
+          std::free(bk.e);
+          bk.e = ne; bk.slots = slots;
+        }
+        bk.used = at;
+        bk.dirty = 1;
+      }
+    };
+    const uint32_t span = (kNumCodes + n_thr - 1) / n_thr;
+    for (uint32_t k = 1; k < n_thr; ++k) th.emplace_back(grow, k * span, std::min(kNumCodes, (k + 1) * span));
+    grow(0, std::min(kNumCodes, span));
+    for (auto& t : th) t.join();
+  }
+
+  stage("grow buckets");
+  // 4. fill: every chunk writes its own slots
+  for_chunks([&](size_t c) {
+    const Chunk& ck = chunks[c];
+    const size_t lo = c * per, hi = std::min(n, lo + per);
+    uint32_t* at = &start[c * kNumCodes];
+    size_t pos = 0;
+    for (size_t i = lo; i < hi; ++i) {
+      if (!take[i]) continue;
+      const uint32_t w0 = weights ? weights[i] : 0u;
+      const Entry e{refs[i], w0 ? w0 : ck.lens[i - lo]};              // storage.c:409
+      for (uint32_t j = 0; j < ck.ncodes[i - lo]; ++j) b_[ck.codes[pos + j]].e[at[ck.codes[pos + j]]++] = e;
+      pos += ck.ncodes[i - lo];
+    }
+  });
+
+  stage("fill");
+  long added = 0;
+  for (const Chunk& ck : chunks) added += ck.added;
+  total_trigrams_ += uint32_t(added);                                 // storage.c:466-467
+  total_refs_ += uint32_t(accepted);
+  ++generation_;
+  return added;
 }
 
 int HostIndex::del(uint32_t ref) {                                // storage.c:584-612

@@ -62,6 +62,12 @@ class HostIndex {
   HostIndex& operator=(const HostIndex&) = delete;
 
   int  put(const char* needle, size_t len, uint32_t ref, uint32_t weight);
+  // n puts in string order with the result (buckets byte for byte, totals) of n calls of put();
+  // tokenising and filling the buckets run on all host cores.  Strings are the C strings at
+  // packed + offsets[i] (at most offsets[i+1] - offsets[i] bytes); weights may be null (all 0).
+  // Returns the trigrams added.
+  long put_many(const char* packed, const uint64_t* offsets, const uint32_t* refs, const uint32_t* weights,
+                size_t n);
   int  del(uint32_t ref);
   int  save(const char* path);                 // 0 / -1+errno
   static HostIndex* load(const char* path);    // nullptr+errno on failure

@@ -328,3 +328,39 @@ def test_reference_loads_and_resaves_our_file_byte_identically(tmp_path):
     again = tmp_path / "again.trigrams"
     RawMap.load(theirs).save(again)                # and we re-save the reference's file identically
     assert md5(again) == md5(ours)
+
+
+def test_bulk_put_many_is_byte_identical_to_single_puts(tmp_path):
+    """Batches of 65 536 strings or more take the parallel host path (HostIndex::put_many): the saved
+    file must equal, byte for byte, what the same puts one at a time leave -- duplicate references
+    inside the batch and against the map, explicit and defaulted weights, buckets that already hold
+    dead slots from deletes, several growth steps."""
+    rng = np.random.default_rng(17)
+    hay, off = W.geonames(90000, 9000, 33)
+    strings = W.unpack(hay, off)
+    n = len(strings)
+    refs = np.arange(1000, 1000 + n, dtype=np.uint32)
+    refs[rng.integers(0, n, size=500)] = refs[rng.integers(0, n, size=500)]      # duplicates inside the batch
+    refs[:50] = np.arange(1, 51, dtype=np.uint32)                                 # and against the map below
+    weights = rng.integers(0, 30, size=n).astype(np.uint32)
+    weights[rng.random(n) < 0.5] = 0
+    a, b = RawMap(), RawMap()
+    for m in (a, b):                                                              # a map with history
+        for r in range(1, 801):
+            m.put(strings[(r * 7) % n], r, r % 5)
+        for r in range(100, 700, 3):
+            m.delete(r)
+    total_a = a.put_many_packed(hay, off, refs, weights)
+    total_b = sum(b.put(s, int(r), int(w)) for s, r, w in zip(strings, refs.tolist(), weights.tolist()))
+    assert total_a == total_b
+    assert a.stats() == b.stats()
+    a.save(tmp_path / "a.trigrams")
+    b.save(tmp_path / "b.trigrams")
+    assert (tmp_path / "a.trigrams").read_bytes() == (tmp_path / "b.trigrams").read_bytes()
+    # and a second bulk on top of the first (buckets now well past their first allocation)
+    hay2, off2 = W.geonames(70000, 9000, 34)
+    refs2 = np.arange(500000, 570000, dtype=np.uint32)
+    assert a.put_many_packed(hay2, off2, refs2) == sum(b.put(s, int(r), 0) for s, r in zip(W.unpack(hay2, off2), refs2))
+    a.save(tmp_path / "a2.trigrams")
+    b.save(tmp_path / "b2.trigrams")
+    assert (tmp_path / "a2.trigrams").read_bytes() == (tmp_path / "b2.trigrams").read_bytes()
