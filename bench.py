@@ -8,12 +8,25 @@ synthetic needles that is already resident in HBM.  At N=1 the workload is
 BASELINE.json configs[2]: the synthetic Geonames-scale haystack (8 423 769 multi-word strings,
 ~118 M trigram entries) and one batch of 1 M needles.  For N>1 (configs[3]) the haystack is
 replicated on every GPU, every rank gets its own 1 M-needle shard (weak scaling) and the
-per-rank result blocks are collected on rank 0 by one RCCL gather inside the timed region.
+per-rank result blocks are collected on rank 0 by ONE RCCL gather inside the timed region.
 
 Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carries
-`roofline` (algorithmic bytes of SURVEY.md section 8(d) over the HIP-event time of the find
-kernels) and, at N=1, `cpu_baseline` (the reference's own C -- oracle/_ref -- timed on one
-host core on a bounded sample of the same needles).
+
+  roofline       the position of the dominant kernel against the HBM roofline, from PHYSICAL
+                 bytes: what the kernels requested of the memory system in one launch -- counted
+                 exactly by the kernels themselves (blurrily_storage_set_stats) in an extra,
+                 untimed launch of this very run -- over the HIP-event kernel time of the timed
+                 steps.  `frac` = that rate / 8 TB/s, always <= 1.  The SURVEY.md section 8(d)
+                 algorithmic figure (the reference's 8 bytes per matched entry) is kept beside it
+                 as algorithmic_*: it exceeds the peak because a posting costs 2 bytes in HBM and
+                 windows / slices that cannot change the answer are never read.  An `lds` line
+                 gives the LDS-atomic rate against the ds_add ceiling of the guide.
+  cpu_baseline   (N=1) the reference's own C -- oracle/_ref -- timed on one host core on a bounded
+                 prefix of the step's needles, whose rows are compared with the rows the GPU wrote
+                 for the same needles in the timed launch: `parity_checked` needles, exit status 1
+                 on any difference.
+  extra_configs  (N=1, default workload) configs[1] and configs[4] of BASELINE.json, a few steps
+                 each, same fields.
 """
 import argparse
 import ctypes as C
@@ -31,16 +44,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (imported before the HIP library so both share one HIP runtime)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-WORKLOADS = {
-    # name: (haystack generator kwargs, needles per rank, limit, BASELINE.json config)
-    "geonames": dict(kind="geonames", n=8423769, vocab=500000, hay_seed=3, queries=1_000_000, limit=10,
-                     label="configs[2]: synthetic Geonames-scale haystack, 1M batched needles"),
-    "words":    dict(kind="words", n=235886, hay_seed=1, queries=100_000, limit=10,
-                     label="configs[1]: 235k-word haystack, 100k batched needles"),
-    "skewed":   dict(kind="skewed", n=4_000_000, hay_seed=5, queries=100_000, limit=100,
-                     label="configs[4]: adversarial hot-trigram haystack, limit=100"),
-}
+# LDS atomics: a no-return ds_add_u32 moves an address and a data VGPR like ds_write_b32, whose rate
+# MI355X_MICROARCH.md (section LDS) gives as 4 cycles per wave-instruction = 16 lanes per clock per
+# CU, bank-conflict free; 256 CUs at 2.4 GHz.
+LDS_ATOMIC_PEAK_LANES = 16 * 256 * 2.4e9
 
 
 def log(msg):
@@ -48,40 +55,37 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def build_haystack(spec, scale):
+def build_haystack(name, scale):
     import workloads as W
     from blurrily_amd import RawMap
-    n = max(1000, int(spec["n"] * scale))
     t0 = time.time()
-    if spec["kind"] == "geonames":
-        hay, off = W.geonames(n, max(1000, int(spec["vocab"] * min(1.0, scale * 4))), spec["hay_seed"])
-    elif spec["kind"] == "words":
-        hay, off = W.words(n, spec["hay_seed"])
-    else:
-        hay, off = W.skewed(n, spec["hay_seed"])
+    hay, off = W.bench_haystack(name, scale)
+    n = len(off) - 1
     t1 = time.time()
     m = RawMap()
-    refs = np.arange(1, n + 1, dtype=np.uint32)
-    entries = m.put_many_packed(hay, off, refs)
+    entries = m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     t2 = time.time()
     m.sync_device()
     t3 = time.time()
-    log(f"haystack: {n} strings, {entries} entries ({entries / n:.2f}/string); "
+    log(f"{name}: {n} strings, {entries} entries ({entries / n:.2f}/string); "
         f"generate {t1 - t0:.1f}s, put {t2 - t1:.1f}s, device index {t3 - t2:.1f}s")
     return m, hay, off, entries
 
 
-def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s):
+def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s, gpu_rows, gpu_counts):
     """The reference's own C (oracle/_ref, kind "reference") -- or, if that build is absent, the
     oracle port -- on ONE host core (the reference is single-threaded), on a bounded prefix of
-    the step's needles.  The haystack reaches the reference as a .trigrams file."""
+    the step's needles.  The haystack reaches the reference as a .trigrams file.  The rows it
+    returns are compared with the GPU's rows for the same needles (parity_checked)."""
     import workloads as W
     from helpers import Oracle, Reference
-    raw = W.unpack(qp, qo[:min(len(qo) - 1, 2048) + 1])
+    cap = min(len(qo) - 1, 2048)
+    raw = W.unpack(qp, qo[:cap + 1])
     packed = np.frombuffer(b"\0".join(raw) + b"\0", dtype=np.uint8)      # C strings
     starts = np.zeros(len(raw), dtype=np.uint32)
     starts[1:] = np.cumsum([len(r) + 1 for r in raw])[:-1]
-    rows = (C.c_uint32 * (3 * max(limit, 1)))()
+    rows = np.zeros((cap, max(limit, 1), 3), dtype=np.uint32)
+    counts = np.zeros(cap, dtype=np.uint32)
     if Reference.available():
         kind = "reference"
         path = f"/tmp/blurrily_bench_{os.getpid()}.trigrams"
@@ -92,7 +96,8 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s):
         def run(lo, hi):
             seg = np.ascontiguousarray(starts[lo:hi])
             t = time.perf_counter()
-            S.ref_find_many(ref.h, packed.ctypes.data, seg.ctypes.data, hi - lo, limit, rows)
+            S.ref_find_many(ref.h, packed.ctypes.data, seg.ctypes.data, hi - lo, limit,
+                            rows[lo:].ctypes.data, counts[lo:].ctypes.data)
             return time.perf_counter() - t
 
         def done():
@@ -106,7 +111,7 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s):
         def run(lo, hi):
             t = time.perf_counter()
             for k in range(lo, hi):
-                o.L.oracle_find(o.h, raw[k], limit, rows)
+                counts[k] = o.L.oracle_find(o.h, raw[k], limit, rows[k].ctypes.data)
             return time.perf_counter() - t
 
         def done():
@@ -116,13 +121,24 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s):
     per = run(0, k) / k
     n = int(max(k, min(len(raw), budget_s / max(per, 1e-7))))
     dt = run(0, n)
+    # ---- parity of the timed GPU launch against these very rows ---------------------------------
+    mismatches = []
+    for i in range(n):
+        c = int(counts[i])
+        if c != int(gpu_counts[i]) or not np.array_equal(rows[i, :c], gpu_rows[i, :c]):
+            mismatches.append(i)
     out = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": kind,
            "sample": f"first {n} needles of the step batch, limit {limit}, one thread "
                      f"(flags of ext/blurrily/extconf.rb: -Os)",
-           "ms_per_query": 1e3 * dt / n}
+           "ms_per_query": 1e3 * dt / n,
+           "parity_checked": n, "parity_mismatches": len(mismatches)}
+    if mismatches:
+        i = mismatches[0]
+        log(f"PARITY MISMATCH at needle {i} {raw[i]!r}: cpu {rows[i, :int(counts[i])].tolist()} "
+            f"gpu {gpu_rows[i, :int(gpu_counts[i])].tolist()}")
     # The reference is single-threaded; for scale, the same read-only map queried by one forked
-    # process per host core (each maps the same file), every process timing the same n needles.
-    if kind == "reference" and hasattr(os, "fork"):
+    # process per host core (each maps the same file), every process timing the same needles.
+    if kind == "reference" and hasattr(os, "fork") and budget_s >= 10:
         try:
             cores = min(os.cpu_count() or 1, 128)
             import multiprocessing as mp
@@ -151,14 +167,186 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s):
     return out
 
 
+def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_budget, latency_probes):
+    """Build the workload, time `steps` steps, derive the figures.  Returns (line dict or None on
+    ranks > 0, parity_ok)."""
+    import workloads as W
+    from blurrily_amd import _native
+    from blurrily_amd.sharding import ResultBlock, gather_blocks
+
+    spec = W.BENCH_WORKLOADS[name]
+    limit = spec["limit"]
+    m, hay, hay_off, entries_resident = build_haystack(name, args.scale)
+    qp, qo = W.bench_needles(hay, hay_off, name, args.scale, rank, world)
+    n_q = len(qo) - 1
+    sum_T = W.count_trigrams(qp, qo)
+
+    dev = torch.device("cuda", local_rank)
+    d_packed = torch.from_numpy(qp).to(dev)
+    d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
+    # this rank's results are ONE buffer (rows | counts) that the kernels fill in place and that the
+    # gather ships as it is (blurrily_amd/sharding.py)
+    block = ResultBlock(n_q, limit, device=dev)
+    d_nb = torch.empty((n_q,), dtype=torch.int32, device=dev)
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = torch.empty((world, block.buf.numel()), dtype=torch.int32, device=dev)
+    lib = _native.lib()
+    m.set_timing(True)
+    stream = torch.cuda.current_stream().cuda_stream
+    kernel_ms, gather_ms = [], []
+
+    def find():
+        res = lib.blurrily_storage_find_batch_device(
+            m.handle, d_packed.data_ptr(), int(qo[-1]), d_off.data_ptr(), n_q, limit,
+            block.rows.data_ptr(), block.counts.data_ptr(), d_nb.data_ptr(), stream)
+        if res < 0:
+            raise RuntimeError(f"find_batch_device failed: errno {C.get_errno()}")
+
+    def step():
+        find()
+        kernel_ms.append(m.device_info()["last_find_kernel_ms"])     # (timing mode: the call has synchronised)
+        if world > 1:
+            t = time.perf_counter()
+            gather_blocks(dist, block, gathered, rank)
+            torch.cuda.synchronize()
+            gather_ms.append(1e3 * (time.perf_counter() - t))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    kernel_ms.clear()
+    gather_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- derived figures (outside the timed region) ----------------------------------------
+    # rows of the LAST TIMED launch, for the parity leg
+    gpu_rows = block.rows.cpu().numpy().view(np.uint32)
+    gpu_counts = block.counts.cpu().numpy().view(np.uint32)
+    nb = d_nb.cpu().numpy().astype(np.uint32).astype(np.int64)
+    sum_nb, sum_rows = int(nb.sum()), int(gpu_counts.astype(np.int64).sum())
+    algo_bytes = 8 * sum_nb + 8 * sum_T + 12 * sum_rows + 4 * n_q            # SURVEY.md 8(d), one launch
+    k_ms = float(np.mean(kernel_ms))
+    # one more launch, untimed, with the kernels' own request counters on: the physical bytes and the
+    # LDS-atomic lanes of exactly this batch
+    m.set_stats(True)
+    find()
+    torch.cuda.synchronize()
+    st = m.find_stats()
+    m.set_stats(False)
+    stats_rows_equal = bool(np.array_equal(gpu_counts, block.counts.cpu().numpy().view(np.uint32)))
+    out_bytes = 12 * sum_rows + 4 * n_q + 4 * n_q                              # rows + counts + nb_entries
+    needle_bytes = int(qo[-1]) + 8 * (n_q + 1) + 2 * (int(qo[-1]) + n_q)       # needles, offsets, code scratch (w+r)
+    phys_bytes = (2 * st["posting_entries"] + 4 * st["table_words"] + 4 * st["bitmap_words"] +
+                  4 * st["probes"] + out_bytes + 2 * needle_bytes)
+    phys_gbs = phys_bytes / (k_ms * 1e-3) / 1e9
+    lds_lanes = st["posting_entries"] / (k_ms * 1e-3)
+
+    totals = torch.tensor([float(sum_nb), k_ms, float(np.mean(gather_ms)) if gather_ms else 0.0],
+                          dtype=torch.float64, device=dev)
+    per_rank = None
+    if world > 1:
+        allr = [torch.zeros_like(totals) for _ in range(world)]
+        dist.all_gather(allr, totals)
+        per_rank = [[float(x) for x in t.tolist()] for t in allr]
+        total_entries = sum(p[0] for p in per_rank)
+    else:
+        total_entries = float(sum_nb)
+
+    out, parity_ok = None, True
+    if rank == 0:
+        # p50 single-needle latency through blurrily_storage_find (host buffers, sync per call)
+        p50_us, host_rate = None, None
+        if latency_probes:
+            raw = W.unpack(qp, qo[:latency_probes + 1])
+            rows = (_native.TrigramMatch * limit)()
+            lat = []
+            for nd in raw:
+                t = time.perf_counter()
+                lib.blurrily_storage_find(m.handle, nd, limit, rows)
+                lat.append(time.perf_counter() - t)
+            p50_us = float(np.median(lat) * 1e6) if lat else None
+            # the same batch through the host-buffer entry point: H2D of the needles and D2H of the
+            # result rows included (reported beside `value`, never as `value`)
+            t = time.perf_counter()
+            m.find_batch_packed(qp, qo, limit)
+            host_rate = n_q / (time.perf_counter() - t)
+        info = m.device_info()
+        out = {
+            "metric": "find() queries/sec (batched), Geonames-scale haystack",
+            "value": world * n_q * steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": spec["label"], "haystack_strings": int(len(hay_off) - 1),
+                       "haystack_entries": int(entries_resident), "needles_per_gpu": n_q, "limit": limit,
+                       "index_replicated": world > 1, "parallelism": f"query-shard x{world}",
+                       "scale": args.scale},
+            "p50_query_us": p50_us,
+            "host_buffer_queries_per_sec": host_rate,
+            "matched_entries_per_sec": total_entries * steps / elapsed,
+            "entries_per_query": sum_nb / n_q,
+            "kernel_ms": k_ms,
+            "roofline": {
+                "bound": "hbm", "achieved": phys_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": phys_gbs / HBM_PEAK_GBS,
+                "traffic": phys_bytes,
+                "traffic_source": "bytes requested by the kernels in one launch of this batch, counted in-kernel "
+                                  "(blurrily_storage_set_stats) in an extra untimed launch of this run; the "
+                                  "rocprofv3 --pmc cross-check is under profiles/",
+                "kernel": "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024"),
+                "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "algorithmic_gbs": algo_bytes / (k_ms * 1e-3) / 1e9,
+                "algorithmic_ratio": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "postings_read_fraction": st["posting_entries"] / max(1, sum_nb),
+                "lds": {"atomic_lanes_per_launch": st["posting_entries"], "atomic_lanes_per_sec": lds_lanes,
+                        "peak_lanes_per_sec": LDS_ATOMIC_PEAK_LANES, "frac": lds_lanes / LDS_ATOMIC_PEAK_LANES},
+                "counters": st,
+                "counted_launch_rows_equal_timed": stats_rows_equal,
+                "resident_index_bytes": int(info["device_bytes"])},
+        }
+        if world > 1:
+            out["per_rank"] = {"kernel_ms": [p[1] for p in per_rank], "gather_ms": [p[2] for p in per_rank]}
+            out["gather_ms"] = float(np.mean(gather_ms))
+            out["gather_bytes_per_rank"] = int(block.buf.numel() * 4)
+        if world == 1 and cpu_budget > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(m, hay, hay_off, qp, qo, limit, cpu_budget, gpu_rows, gpu_counts)
+                parity_ok = out["cpu_baseline"]["parity_mismatches"] == 0
+                out["parity_checked"] = out["cpu_baseline"]["parity_checked"]
+            except Exception as e:  # the GPU numbers stand on their own
+                out["cpu_baseline"] = {"error": str(e)}
+    m.close()
+    return out, parity_ok
+
+
 def main():
+    import workloads as W
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="geonames", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(W.BENCH_WORKLOADS),
+                    help="default: geonames (configs[2]) plus, at N=1, configs[1] and [4] as extra_configs")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink haystack and batch (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--latency-probes", type=int, default=200)
     args = ap.parse_args()
@@ -177,138 +365,34 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # every rank builds the same (seeded) haystack: share the host's cores between the ranks
+        os.environ.setdefault("BLURRILY_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    import workloads as W
-    from blurrily_amd import _native
-    from blurrily_amd.sharding import gather_results
-
-    spec = dict(WORKLOADS[args.workload])
-    limit = spec["limit"]
-    n_q = max(100, int(spec["queries"] * args.scale))
-    m, hay, hay_off, entries_resident = build_haystack(spec, args.scale)
-    # this rank's shard of the global batch (world x n_q needles, contiguous shards)
-    q_seed = (3 if world == 1 else 4) * 1000 + rank
-    qp, qo = W.queries(hay, hay_off, n_q, q_seed)
-    sum_T = W.count_trigrams(qp, qo)
-
-    dev = torch.device("cuda", local_rank)
-    d_packed = torch.from_numpy(qp).to(dev)
-    d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
-    d_results = torch.empty((n_q, limit, 3), dtype=torch.int32, device=dev)
-    d_counts = torch.empty((n_q,), dtype=torch.int32, device=dev)
-    d_nb = torch.empty((n_q,), dtype=torch.int32, device=dev)
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = (torch.empty((world, n_q, limit, 3), dtype=torch.int32, device=dev),
-                    torch.empty((world, n_q), dtype=torch.int32, device=dev))
-    lib = _native.lib()
-    m.set_timing(True)
-    stream = torch.cuda.current_stream().cuda_stream
-    kernel_ms = []
-
-    def step():
-        res = lib.blurrily_storage_find_batch_device(
-            m.handle, d_packed.data_ptr(), int(qo[-1]), d_off.data_ptr(), n_q, limit,
-            d_results.data_ptr(), d_counts.data_ptr(), d_nb.data_ptr(), stream)
-        if res < 0:
-            raise RuntimeError(f"find_batch_device failed: errno {C.get_errno()}")
-        kernel_ms.append(m.device_info()["last_find_kernel_ms"])
-        if world > 1:
-            gather_results(dist, d_results, d_counts, gathered, rank)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- derived figures (outside the timed region) ----------------------------------------
-    nb = d_nb.cpu().numpy().astype(np.uint32).astype(np.int64)
-    counts = d_counts.cpu().numpy().astype(np.int64)
-    sum_nb, sum_rows = int(nb.sum()), int(counts.sum())
-    algo_bytes = 8 * sum_nb + 8 * sum_T + 12 * sum_rows + 4 * n_q            # SURVEY.md 8(d), one launch
-    k_ms = float(np.mean(kernel_ms))
-    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-    totals = torch.tensor([float(sum_nb)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(totals)
-    total_entries = float(totals.item())
-
-    out = None
-    if rank == 0:
-        # p50 single-needle latency through blurrily_storage_find (host buffers, sync per call)
-        raw = W.unpack(qp, qo[:args.latency_probes + 1])
-        rows = (_native.TrigramMatch * limit)()
-        lat = []
-        for nd in raw:
-            t = time.perf_counter()
-            lib.blurrily_storage_find(m.handle, nd, limit, rows)
-            lat.append(time.perf_counter() - t)
-        p50_us = float(np.median(lat) * 1e6) if lat else None
-        # the same batch through the host-buffer entry point: H2D of the needles and D2H of the
-        # result rows included (reported beside `value`, never as `value`)
-        t = time.perf_counter()
-        m.find_batch_packed(qp, qo, limit)
-        host_rate = n_q / (time.perf_counter() - t)
-        info = m.device_info()
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and args.scale == 1.0:      # measured on the full workload only
+    main_name = args.workload or "geonames"
+    budget = 0.0 if args.no_cpu_baseline else args.cpu_budget
+    out, ok = run_workload(main_name, args, args.steps, args.warmup, rank, local_rank, world, dist, budget,
+                           args.latency_probes)
+    if world == 1 and args.workload is None and not args.no_extra:
+        extra = {}
+        for name in ("words", "skewed"):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "find() queries/sec (batched), Geonames-scale haystack",
-            "value": world * n_q * args.steps / elapsed,
-            "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": spec["label"], "haystack_strings": int(len(hay_off) - 1),
-                       "haystack_entries": int(entries_resident), "needles_per_gpu": n_q, "limit": limit,
-                       "index_replicated": world > 1, "parallelism": f"query-shard x{world}",
-                       "scale": args.scale},
-            "p50_query_us": p50_us,
-            "host_buffer_queries_per_sec": host_rate,
-            "matched_entries_per_sec": total_entries * args.steps / elapsed,
-            "entries_per_query": sum_nb / n_q,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # the physical stream: PMC bytes per launch (a separate rocprofv3 --pmc run of this
-                         # workload, profiles/) over this run's kernel time, against the same peak
-                         "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024"),
-                         "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "resident_index_bytes": int(info["device_bytes"])},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(m, hay, hay_off, qp, qo, limit, args.cpu_budget)
-            except Exception as e:  # the GPU numbers stand on their own
-                out["cpu_baseline"] = {"error": str(e)}
+                line, ok_x = run_workload(name, args, max(3, min(args.steps, 10)), 1, rank, local_rank, world, dist,
+                                          min(budget, 4.0), min(args.latency_probes, 50))
+                ok = ok and ok_x
+                extra[name] = {k: line[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "p50_query_us",
+                                                    "matched_entries_per_sec", "entries_per_query", "kernel_ms",
+                                                    "roofline", "cpu_baseline", "parity_checked") if k in line}
+            except Exception as e:
+                extra[name] = {"error": str(e)}
+        out["extra_configs"] = extra
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

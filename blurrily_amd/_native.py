@@ -101,6 +101,8 @@ def lib():
         "blurrily_tokeniser_parse_string": (C.c_int, [C.c_char_p, C.c_void_p]),
         "blurrily_storage_device_info": (C.c_int, [vp, C.POINTER(DeviceInfo)]),
         "blurrily_storage_set_timing": (None, [vp, C.c_int]),
+        "blurrily_storage_set_stats": (None, [vp, C.c_int]),
+        "blurrily_storage_find_stats": (C.c_int, [vp, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -117,4 +119,5 @@ EXPORTED_SYMBOLS = (
     "blurrily_storage_find_batch_device", "blurrily_storage_find_batch_raw", "blurrily_normalize_batch_device",
     "blurrily_storage_sync_device", "blurrily_tokeniser_parse_string",
     "blurrily_storage_device_info", "blurrily_storage_set_timing",
+    "blurrily_storage_set_stats", "blurrily_storage_find_stats",
 )

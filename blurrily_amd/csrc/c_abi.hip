@@ -32,6 +32,26 @@ namespace {
     }                                                                                 \
   } while (0)
 
+// A map's device image lives on the HIP device that was current when it was built.  Every entry
+// point that touches the image runs inside a DeviceScope: the current device is switched to the
+// map's and restored on the way out, so a caller (torch, another map) may leave any device current.
+struct DeviceScope {
+  int  prev = -1;
+  bool changed = false;
+  explicit DeviceScope(int want) {
+    if (want >= 0 && hipGetDevice(&prev) == hipSuccess && prev != want) changed = hipSetDevice(want) == hipSuccess;
+  }
+  ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+// deletes since the last find: set their bits in the tombstone bitmap, in stream order with the find
+__global__ void apply_tombstones_kernel(uint32_t* __restrict__ tomb, const uint32_t* __restrict__ ranks, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicOr(&tomb[ranks[i] >> 5], 1u << (ranks[i] & 31));
+}
+
 // Device scratch that lives as long as the map and only ever grows.
 struct DeviceBuffer {
   void*  p = nullptr;
@@ -61,8 +81,12 @@ struct trigram_map_t {
   // log of puts/deletes the base image does not contain yet
   std::unordered_map<uint32_t, PendingPut> pending;   // by reference
   size_t      n_tomb = 0;               // base references deleted since the build
+  std::vector<uint32_t> tomb_queue;     // their ranks, not yet on the device (applied by the next find, on its stream)
+  DeviceBuffer ws_tomb;
   uint64_t    log_version = 0;          // bumped by every logged mutation
   uint64_t    delta_version = 0;        // log_version the delta image / code totals were built from
+  uint64_t    delta_puts_version = 0;   // bumped when the set of pending puts changes (the delta image's content)
+  uint64_t    delta_image_version = 0;  // delta_puts_version the delta image was built from
   bool        log_overflow = false;     // the log outgrew its budget: the next find rebuilds the base
   uint64_t    base_builds = 0;
   HostIndex*  delta_host = nullptr;
@@ -71,6 +95,8 @@ struct trigram_map_t {
   DeviceBuffer ws_base_rows, ws_base_counts, ws_delta_rows, ws_delta_counts;
   int         n_cus = 0;
   bool        timing = false;
+  bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
+  unsigned long long* d_stats = nullptr;   // [kStatSlots], zeroed by every run_find while collecting
   double      last_find_ms = 0.0, last_tok_ms = 0.0;
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_in, ws_io_out;
@@ -88,6 +114,7 @@ size_t log_budget(const trigram_map m) { return std::max<size_t>(4096, m->dev.n_
 void clear_log(trigram_map m) {
   m->pending.clear();
   m->n_tomb = 0;
+  m->tomb_queue.clear();
   m->log_overflow = false;
   ++m->log_version;
   m->delta_version = m->log_version;
@@ -115,12 +142,17 @@ int ensure_device(trigram_map m) {
     return 0;
   }
   if (log_empty(m) || m->delta_version == m->log_version) return 0;
-  // rebuild the delta image and refresh the whole-map bucket sizes
-  delete m->delta_host;
-  m->delta_host = new HostIndex();
-  for (const auto& kv : m->pending)
-    m->delta_host->put(kv.second.needle.data(), kv.second.needle.size(), kv.first, kv.second.weight);
-  if (device_index_build(*m->delta_host, &m->delta) < 0) return -1;
+  // The delta host index is kept in step by log_put / log_delete; its device image is rebuilt only
+  // when the set of pending puts changed (a delete of a base reference is a tombstone, no rebuild).
+  if (m->delta_image_version != m->delta_puts_version) {
+    if (m->pending.empty()) {
+      if (m->delta.device >= 0) device_index_free(&m->delta);
+    } else if (device_index_build(*m->delta_host, &m->delta) < 0) {
+      return -1;
+    }
+    m->delta_image_version = m->delta_puts_version;
+  }
+  // whole-map bucket sizes (nb_entries of the base run)
   std::vector<uint32_t> totals(kNumCodes);
   for (uint32_t t = 0; t < kNumCodes; ++t) totals[t] = m->host->bucket(t).used;
   if (!m->d_code_total_now)
@@ -139,22 +171,41 @@ void log_put(trigram_map m, const char* needle, size_t len, uint32_t ref, uint32
     return;
   }
   m->pending[ref] = PendingPut{std::string(needle, len), weight};
+  if (!m->delta_host) m->delta_host = new HostIndex();
+  m->delta_host->put(needle, len, ref, weight);
+  ++m->delta_puts_version;
   ++m->log_version;
 }
 
 int log_delete(trigram_map m, uint32_t ref) {
   if (m->dev.device < 0 || m->log_overflow) return 0;
   ++m->log_version;
-  if (m->pending.erase(ref)) return 0;                 // never reached the base image
+  if (m->pending.erase(ref)) {                         // never reached the base image
+    if (m->delta_host) m->delta_host->del(ref);
+    ++m->delta_puts_version;
+    return 0;
+  }
   const int64_t rk = device_index_rank_of(m->dev, ref);
   if (rk < 0) return 0;
-  // set the tombstone bit on the device (stream-ordered with later finds on the default stream)
-  uint32_t word = 0;
-  uint32_t* d_word = m->dev.d_tomb + (rk >> 5);
-  BLURRILY_HIP_TRY(hipMemcpy(&word, d_word, sizeof(word), hipMemcpyDeviceToHost));
-  word |= 1u << (rk & 31);
-  BLURRILY_HIP_TRY(hipMemcpy(d_word, &word, sizeof(word), hipMemcpyHostToDevice));
+  // the tombstone bit is set by the next find, on that find's stream (apply_tombstones): no
+  // synchronous round trip per delete, and ordered with whatever stream the caller finds on
+  m->tomb_queue.push_back(uint32_t(rk));
   ++m->n_tomb;
+  return 0;
+}
+
+// Upload the queued tombstone ranks and set their bits, ordered before the find on `stream`.
+int apply_tombstones(trigram_map m, hipStream_t stream) {
+  if (m->tomb_queue.empty()) return 0;
+  const size_t n = m->tomb_queue.size();
+  if (m->ws_tomb.reserve(n * sizeof(uint32_t), stream) < 0) return -1;
+  // (pageable source: the runtime stages it before returning, the queue can be cleared right away)
+  BLURRILY_HIP_TRY(hipMemcpyAsync(m->ws_tomb.p, m->tomb_queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  stream));
+  hipLaunchKernelGGL(apply_tombstones_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, stream, m->dev.d_tomb,
+                     static_cast<const uint32_t*>(m->ws_tomb.p), uint32_t(n));
+  BLURRILY_HIP_TRY(hipGetLastError());
+  m->tomb_queue.clear();
   return 0;
 }
 
@@ -205,6 +256,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   a.q_ntri = q_ntri; a.q_nb = q_nb; a.q_start = q_start; a.win_max_tri = ix.d_win_max_tri; a.nib_windows = ix.nib_windows; a.results = d_results; a.counts = d_counts; a.limit = limit;
   a.floor = floor;
   a.tomb = d_tomb;
+  a.stats = m->collect_stats ? m->d_stats : nullptr;
 #ifdef BLURRILY_PHASE_PROFILE
   {
     static unsigned long long* d_phase = nullptr;
@@ -305,6 +357,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
 int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
              uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long,
              bool maybe_mid, hipStream_t stream) {
+  if (m->collect_stats) {
+    if (!m->d_stats) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), kStatSlots * 8));
+    BLURRILY_HIP_TRY(hipMemsetAsync(m->d_stats, 0, kStatSlots * 8, stream));
+  }
+  if (apply_tombstones(m, stream) < 0) return -1;
   if (log_empty(m))
     return run_find_on(m, m->dev, m->dev.d_code_total, nullptr, d_packed, packed_bytes, d_offsets, n, limit,
                        d_results, d_counts, d_nb, maybe_long, maybe_mid, stream);
@@ -356,6 +413,7 @@ int blurrily_storage_load(trigram_map* haystack, const char* path) {
 int blurrily_storage_close(trigram_map* haystack) {
   trigram_map m = *haystack;
   if (m) {
+    DeviceScope scope(m->dev.device);
     if (m->dev.device >= 0) {
       (void)hipDeviceSynchronize();
       device_index_free(&m->dev);
@@ -363,10 +421,11 @@ int blurrily_storage_close(trigram_map* haystack) {
     if (m->delta.device >= 0) device_index_free(&m->delta);
     delete m->delta_host;
     if (m->d_code_total_now) (void)hipFree(m->d_code_total_now);
+    if (m->d_stats) (void)hipFree(m->d_stats);
     m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
-    m->ws_io_out.release();
+    m->ws_io_out.release(); m->ws_tomb.release();
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     delete m->host;
     delete m;
@@ -422,6 +481,7 @@ int blurrily_storage_stats(trigram_map haystack, trigram_stat_t* stats) {
 }
 
 int blurrily_storage_sync_device(trigram_map haystack) {
+  DeviceScope scope(haystack->dev.device);
   haystack->host->sort_dirty_buckets();
   return ensure_device(haystack);
 }
@@ -433,6 +493,7 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
   // The needles are not visible to the host here, so every dirty bucket is
   // sorted (the reference sorts only the needle's own, storage.c:516; results
   // are identical, see DESIGN.md "Mutation and device sync").
+  DeviceScope scope(m->dev.device);
   if (m->host->dirty_buckets()) m->host->sort_dirty_buckets();
   if (ensure_device(m) < 0) return -1;
   if (m->timing && !m->ev[0])
@@ -448,6 +509,7 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
 static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                            trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii) {
   if (n == 0) return 0;
+  DeviceScope scope(m->dev.device);
   // what the reference's find does first: tokenise, sort the needle's dirty buckets
   size_t max_len = 0;
   const bool any_dirty = m->host->dirty_buckets() != 0;
@@ -577,6 +639,17 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
 }
 
 void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabled != 0; }
+
+void blurrily_storage_set_stats(trigram_map m, int enabled) { m->collect_stats = enabled != 0; }
+
+int blurrily_storage_find_stats(trigram_map m, uint64_t* out8) {
+  std::memset(out8, 0, kStatSlots * 8);
+  if (!m->d_stats) return 0;
+  DeviceScope scope(m->dev.device);
+  BLURRILY_HIP_TRY(hipDeviceSynchronize());
+  BLURRILY_HIP_TRY(hipMemcpy(out8, m->d_stats, kStatSlots * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 #ifdef BLURRILY_PHASE_PROFILE
 // profiling builds only: copy out the per-workgroup phase clocks of the last find launch

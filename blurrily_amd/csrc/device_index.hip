@@ -108,7 +108,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     t_last = now;
   };
 
-  const unsigned n_threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  unsigned n_threads = host_threads();
 
   // ---- 1. reference table: every live reference once, ascending ------------
   // Each string owns exactly one leading trigram "**c" (code 784*sym(c)), so
@@ -117,6 +117,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   uint64_t lead = 0, nnz = 0;
   for (uint32_t s = 0; s + 1 < uint32_t(kBase); ++s) lead += host.bucket(s * kBase * kBase).used;
   for (uint32_t t = 0; t < kNumCodes; ++t) nnz += host.bucket(t).used;
+  // a small image (the delta image of a few pending puts above all) is not worth a thread pool
+  n_threads = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(n_threads, nnz / 32768)));
   if (lead == host.total_refs()) {
     refs.reserve(lead);
     for (uint32_t s = 0; s + 1 < uint32_t(kBase); ++s) {

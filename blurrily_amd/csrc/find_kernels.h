@@ -62,6 +62,20 @@ struct FindArgs {
   unsigned long long* part_keys;   // [n_items * ranges * keep] best keys of every task
   uint32_t*       part_count;  // [n_items * ranges]
   unsigned long long* phase_clocks;  // profiling builds only (make profile), else nullptr
+  // optional request counters of a launch (nullptr: off; see kStat* below) -- what the kernels asked of
+  // the memory system and of the LDS, counted exactly from wave-uniform values
+  unsigned long long* stats;
+};
+
+// slots of FindArgs::stats
+enum : uint32_t {
+  kStatPostingEntries = 0,   // 16-bit postings loaded (x2 = bytes); each is also one LDS-atomic lane
+  kStatSteps          = 1,   // sweep steps (count -> barrier -> scan -> barrier)
+  kStatTableWords     = 2,   // slice_off words loaded (x4 = bytes)
+  kStatTasks          = 3,   // needles (or needle ranges) swept
+  kStatCompactions    = 4,   // candidate-pool compactions
+  kStatResweeps       = 5,   // windows swept again after a pool overflow
+  kStatSlots          = 8,
 };
 
 uint32_t find_pool_cap(uint32_t keep);

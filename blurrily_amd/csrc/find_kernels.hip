@@ -453,6 +453,13 @@ __device__ __forceinline__ void bump_unit(uint32_t* cnt32, const uint4 v, uint32
   }
 }
 
+// request counters (FindArgs::stats) for the sweeps that load per lane: postings of one wave-load
+__device__ __forceinline__ void stat_unit(unsigned long long* stats, const uint4 v) {
+  if (!stats) return;
+  const unsigned long long m = __ballot((v.x & 0xFFFFu) != kPadRank);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(&stats[kStatPostingEntries], 8ull * __popcll(m));
+}
+
 __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uint32_t b) {
   uint4 v = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   if (c < b) v = *reinterpret_cast<const uint4*>(ent + c);
@@ -640,6 +647,7 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
   // compact when the pool fills up -- or as soon as it holds `keep` candidates for the first
   // time, so that a threshold exists from then on
   if (!(ov || pn > A.pool_cap / 2 || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
+  if (A.stats && threadIdx.x == 0) atomicAdd(&A.stats[kStatCompactions], 1ull);
   compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
   if (!ov) return false;
   // The pool overflowed mid-window: candidates of this window were lost.  Keep the
@@ -675,8 +683,11 @@ __device__ __forceinline__ bool count_window(const FindArgs& A, uint32_t* cnt32,
     if (a == b) continue;
     any = true;
     const uint32_t su = slice_units(a, b);
-    for (uint32_t j = (wid - t) & (kNW - 1); j < su; j += kNW)
-      bump8<CT>(cnt32, load_group(A.ent, a + (j * 64 + lane) * 8, b));
+    for (uint32_t j = (wid - t) & (kNW - 1); j < su; j += kNW) {
+      const uint4 v = load_group(A.ent, a + (j * 64 + lane) * 8, b);
+      stat_unit(A.stats, v);
+      bump8<CT>(cnt32, v);
+    }
   }
   return any;
 }
@@ -770,15 +781,15 @@ __device__ __forceinline__ bool head_units(uint32_t a0, uint32_t b0, uint32_t a1
 template <typename CT, int kNW>
 __device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32, uint32_t a0, uint32_t b0,
                                            uint32_t a1, uint32_t b1, bool two_slots, uint32_t wid,
-                                           uint32_t lane, uint32_t skip) {
+                                           uint32_t lane, uint32_t skip, unsigned long long* stats) {
   uint32_t k = 0;
   uint4 pend = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, {
-    if (k >= skip) { const uint4 v = load_group(ent, c, sb); bump8<CT>(cnt32, pend); pend = v; }
+    if (k >= skip) { const uint4 v = load_group(ent, c, sb); stat_unit(stats, v); bump8<CT>(cnt32, pend); pend = v; }
   });
   if (two_slots)
     BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, {
-      if (k >= skip) { const uint4 v = load_group(ent, c, sb); bump8<CT>(cnt32, pend); pend = v; }
+      if (k >= skip) { const uint4 v = load_group(ent, c, sb); stat_unit(stats, v); bump8<CT>(cnt32, pend); pend = v; }
     });
   bump8<CT>(cnt32, pend);
 }
@@ -854,12 +865,15 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
       // ---- count window w: its head was loaded one window ago ---------------------------
       PHASE_UNIT(u0); PHASE_UNIT(u1); PHASE_UNIT(u2);
       if (KP > 3) PHASE_UNIT(u3);
+      stat_unit(A.stats, u0); stat_unit(A.stats, u1); stat_unit(A.stats, u2);
+      if (KP > 3) stat_unit(A.stats, u3);
+      if (A.stats && tid == 0) atomicAdd(&A.stats[kStatSteps], 1ull);
       bump8<CT>(cnt32, u0);
       bump8<CT>(cnt32, u1);
       bump8<CT>(cnt32, u2);
       if (KP > 3) bump8<CT>(cnt32, u3);
       PHASE_MARK(1);                                            // head counted
-      if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre);
+      if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre, A.stats);
       PHASE_MARK(2);                                            // rest counted
       __syncthreads();                                          // counts visible
       PHASE_MARK(3);                                            // barrier after count
@@ -880,7 +894,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
         if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
-        count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u);   // overflow: again
+        count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u, A.stats);   // overflow: again
         __syncthreads();
       }
       PHASE_MARK(7);                                            // select / compaction
@@ -953,6 +967,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   do {                                                                           \
     A0 = B0 = A1 = B1 = 0;                                                       \
     const uint32_t w_ = (p_) * kWPS;                                             \
+    if (A.stats && w_ < w1) st_tab += 2u * tc * (kNib && w_ + 1 < w1 ? 2u : 1u); \
     if (w_ < w1 && own) {                                                        \
       const uint32_t idx_ = w_ * kNumCodes + code;                               \
       A0 = A.slice_off[idx_]; B0 = A.slice_off[idx_ + 1];                        \
@@ -989,8 +1004,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   do {                                                                           \
     const uint2 d_ = ring->desc[s_][k_];                                         \
     const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                    \
+    const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                    \
     H = x_ & 1u;                                                                 \
-    U = load_group(A.ent, (x_ & ~7u) + lane * 8, __builtin_amdgcn_readfirstlane(d_.y)); \
+    U = load_group(A.ent, (x_ & ~7u) + lane * 8, y_);                            \
+    if (A.stats) st_ent += min(512u, y_ - (x_ & ~7u));                           \
   } while (0)
   // the units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
   // atomics run while the next unit's load is in flight
@@ -1012,10 +1029,12 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     uint32_t fa0_, fb0_, fa1_, fb1_, k_ = 0;                                     \
     BLURRILY_FETCH_TABLE(p_, fa0_, fb0_, fa1_, fb1_);                            \
     BLURRILY_FOR_SLOT_UNITS(kNW, fa0_, fb0_, wid, lane, k_,                      \
-                            { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 0u); }); \
+                            { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 0u);   \
+                              if (A.stats) st_ent += min(512u, sb - (c - lane * 8)); }); \
     if (kNib)                                                                    \
       BLURRILY_FOR_SLOT_UNITS(kNW, fa1_, fb1_, wid, lane, k_,                    \
-                              { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); }); \
+                              { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); \
+                                if (A.stats) st_ent += min(512u, sb - (c - lane * 8)); }); \
   } while (0)
 #if BLURRILY_COOP_ROTATE
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
@@ -1025,6 +1044,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
+  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0;    // request counters (FindArgs::stats), wave-uniform
   uint32_t i_cur = 0, i_next, i_next2;
   // prologue: one wave publishes the first step, everyone agrees on the second
   if (wid == BLURRILY_PRODUCER(0u)) {
@@ -1041,6 +1061,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     const uint32_t wbase = p * kWPS * kWindowRanks;
     const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
     const uint32_t n_units = ring->n_units[s];
+    ++st_steps;
     PHASE_MARK(0);                                              // loop overhead
     // ---- count step p --------------------------------------------------------------------
     if (n_units == kRingOverflow) {
@@ -1068,6 +1089,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
         if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
+        ++st_redo;
         if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
         else BLURRILY_COUNT_UNITS(s, n_units);
         __syncthreads();
@@ -1077,6 +1099,14 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     i_next = i_next2;
   }
   PHASE_FLUSH(A);
+  if (A.stats && lane == 0) {
+    atomicAdd(&A.stats[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    atomicAdd(&A.stats[kStatTableWords], static_cast<unsigned long long>(st_tab));
+    if (wid == 0) {
+      atomicAdd(&A.stats[kStatSteps], static_cast<unsigned long long>(st_steps));
+      atomicAdd(&A.stats[kStatResweeps], static_cast<unsigned long long>(st_redo));
+    }
+  }
   __syncthreads();                                              // ring and ctl quiet before the needle ends
 #undef BLURRILY_PRODUCER
 #undef BLURRILY_COUNT_WALK
@@ -1162,6 +1192,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     __syncthreads();
 
     PHASE_NEEDLE(10);
+    if (A.stats && tid == 0) atomicAdd(&A.stats[kStatTasks], 1ull);
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \

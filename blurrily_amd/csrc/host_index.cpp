@@ -17,6 +17,15 @@
 
 namespace blurrily {
 
+unsigned host_threads() {
+  unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  if (const char* e = std::getenv("BLURRILY_HOST_THREADS")) {
+    const long v = std::atol(e);
+    if (v >= 1) n = unsigned(std::min<long>(v, 256));
+  }
+  return n;
+}
+
 namespace {
 
 constexpr size_t   kPage          = 4096;               // storage.c:29
@@ -200,7 +209,7 @@ long HostIndex::put_many(const char* packed, const uint64_t* offsets, const uint
 
   // 2. tokenise in parallel, chunk by chunk: codes of every stored string, and how many entries
   //    each chunk adds to each bucket
-  const size_t n_chunks = std::max<size_t>(1, std::min<size_t>({size_t(std::thread::hardware_concurrency()), 64, n / 4096 + 1}));
+  const size_t n_chunks = std::max<size_t>(1, std::min<size_t>(size_t(host_threads()), n / 4096 + 1));
   const size_t per = (n + n_chunks - 1) / n_chunks;
   struct Chunk { std::vector<uint16_t> codes; std::vector<uint32_t> ncodes, lens; std::vector<uint32_t> hist; long added = 0; };
   std::vector<Chunk> chunks(n_chunks);

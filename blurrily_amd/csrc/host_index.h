@@ -54,6 +54,10 @@ class RefSet {
   uint64_t  cap_ = 0, live_ = 0, filled_ = 0;
 };
 
+// Host threads for bulk work (put_many, the device-image transform): the hardware threads, at most
+// 64, or BLURRILY_HOST_THREADS when set (several ranks on one host share its cores).
+unsigned host_threads();
+
 class HostIndex {
  public:
   HostIndex();

@@ -207,6 +207,22 @@ class RawMap:
         self._check_open()
         self._lib.blurrily_storage_set_timing(self._h, 1 if enabled else 0)
 
+    STAT_NAMES = ("posting_entries", "steps", "table_words", "tasks", "compactions", "resweeps",
+                  "bitmap_words", "probes")
+
+    def set_stats(self, enabled):
+        """Request counters of the find kernels on/off (include/blurrily_storage.h)."""
+        self._check_open()
+        self._lib.blurrily_storage_set_stats(self._h, 1 if enabled else 0)
+
+    def find_stats(self):
+        """Counters of the last find call made while set_stats(True): a dict by STAT_NAMES."""
+        self._check_open()
+        out = (C.c_uint64 * 8)()
+        if self._lib.blurrily_storage_find_stats(self._h, out) < 0:
+            _raise_errno()
+        return dict(zip(self.STAT_NAMES, (int(v) for v in out)))
+
     @property
     def handle(self):
         self._check_open()

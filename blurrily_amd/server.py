@@ -20,6 +20,11 @@ from .defaults import DEFAULT_PORT
 from .map_group import MapGroup
 
 
+MAX_LINE_BYTES = 64 * 1024      # longest command line accepted (a needle is tens of bytes)
+MAX_PENDING = 4096              # reads queued for the dispatcher before connections are paused
+RUBY_STRIP = " \t\r\n\f\v\0"   # what String#strip removes
+
+
 class Server:
     def __init__(self, host="0.0.0.0", port=DEFAULT_PORT, directory=None, max_batch=8192, coalesce=True,
                  save_interval=60.0):
@@ -45,7 +50,7 @@ class Server:
         self._stopping = asyncio.Event()
         for sig in (signal.SIGINT, signal.SIGTERM):
             loop.add_signal_handler(sig, self._stopping.set)
-        loop.add_signal_handler(signal.SIGUSR1, self._map_group.save)
+        loop.add_signal_handler(signal.SIGUSR1, lambda: asyncio.ensure_future(self._save()))
         self._server = await asyncio.start_server(self._handle, self._host, self._port)
         self.port = self._server.sockets[0].getsockname()[1]
         dispatcher = asyncio.ensure_future(self._dispatch())
@@ -59,17 +64,33 @@ class Server:
             await self._server.wait_closed()
             saver.cancel()
             dispatcher.cancel()
-            self._map_group.save()                                   # shutdown hook (server.rb:25)
-            self._gpu.shutdown(wait=True)
+            # shutdown hook (server.rb:25): queued behind the batch in flight on the one worker
+            # thread, so it sees every mutation that was acknowledged
+            try:
+                await self._save()
+            finally:
+                self._gpu.shutdown(wait=True)
 
     def stop(self):
         if self._stopping is not None:
             self._stopping.set()
 
+    async def _save(self):
+        """MapGroup#save on the worker thread that runs every PUT / DELETE / FIND: the reference's
+        reactor is single-threaded (server.rb:19-30), so a save never overlaps a mutation or the
+        bucket sort of a find; here the one-worker executor gives the same guarantee (ctypes calls
+        release the GIL, so a save on the event-loop thread would race the worker)."""
+        await asyncio.get_running_loop().run_in_executor(self._gpu, self._map_group.save)
+
     async def _periodic_save(self):                                  # server.rb:23-24
         while True:
             await asyncio.sleep(self._save_interval)
-            self._map_group.save()
+            try:
+                await self._save()
+            except asyncio.CancelledError:
+                raise
+            except Exception as e:                                   # one failed save must not end the saver
+                print(f"blurrily: periodic save failed: {e}", flush=True)
 
     # ---- one connection ------------------------------------------------------------------------
     async def _handle(self, reader, writer):
@@ -96,10 +117,18 @@ class Server:
                 if not data:
                     break
                 *complete, tail = (tail + data).split(b"\n")
+                if len(tail) > MAX_LINE_BYTES:                       # a client that never sends a newline
+                    fut = loop.create_future()
+                    fut.set_result([reply_error("line too long")])
+                    replies.put_nowait(fut)
+                    break
                 # server.rb:41-42: data.split("\n") -- a blank line yields no command -- then strip
-                lines = [ln.decode("utf-8", "replace").strip() for ln in complete if ln]
+                # (String#strip: ASCII whitespace and NUL only, not Unicode spaces)
+                lines = [ln.decode("utf-8", "replace").strip(RUBY_STRIP) for ln in complete if ln]
                 if not lines:
                     continue
+                while len(self._pending) > MAX_PENDING:              # backpressure: stop reading this socket
+                    await asyncio.sleep(0.001)
                 fut = loop.create_future()
                 replies.put_nowait(fut)
                 self._pending.append((lines, fut))

@@ -163,6 +163,18 @@ int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* i
  * launch stream and synchronises to fill last_*_kernel_ms (bench/profiling). */
 void blurrily_storage_set_timing(trigram_map haystack, int enabled);
 
+/* Request counters of the find kernels (bench/profiling; no reference counterpart).  While
+ * enabled, every find launch sequence counts -- exactly, from wave-uniform values -- what it
+ * asks of the memory system and of the LDS; blurrily_storage_find_stats synchronises the
+ * device and copies the counters of the LAST find call into out8[8]:
+ *   [0] 16-bit postings loaded (x 2 = bytes; each is also one LDS-atomic lane)
+ *   [1] sweep steps   [2] slice-table words loaded (x 4 = bytes)   [3] needles (or ranges) swept
+ *   [4] candidate-pool compactions   [5] windows swept again after a pool overflow
+ *   [6] bitmap words loaded (x 4 = bytes)   [7] candidate probes
+ * Collecting costs a few scalar instructions per wave-load; leave it off when timing. */
+void blurrily_storage_set_stats(trigram_map haystack, int enabled);
+int  blurrily_storage_find_stats(trigram_map haystack, uint64_t* out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
  * blurrily_storage_save) through the reference's own blurrily_storage_load.
  */
 #include <dlfcn.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -53,12 +54,17 @@ int ref_find(void* map, const char* needle, uint16_t limit, void* results) {
 }
 int ref_stats(void* map, uint32_t* out2)                  { return g_stats(map, out2); }
 
-/* Timed loop for bench.py's cpu_baseline leg (kind "reference"): runs `n`
- * finds over NUL-separated needles and returns the summed result count so the
- * calls cannot be optimised away.  Timing is done by the caller. */
+/* Loop for bench.py's cpu_baseline leg (kind "reference"): runs `n` finds over
+ * NUL-separated needles, KEEPING every needle's rows (rows[i*limit ..], counts[i])
+ * so that the caller can compare them with the GPU's rows for the same needles.
+ * Returns the summed result count.  Timing is done by the caller. */
 long ref_find_many(void* map, const char* packed, const uint32_t* offsets, int n,
-                   uint16_t limit, void* results_scratch) {
+                   uint16_t limit, void* rows, uint32_t* counts) {
   long total = 0;
-  for (int i = 0; i < n; ++i) total += g_find(map, packed + offsets[i], limit, results_scratch);
+  for (int i = 0; i < n; ++i) {
+    int c = g_find(map, packed + offsets[i], limit, (char*)rows + (size_t)i * limit * 12);
+    counts[i] = (uint32_t)(c < 0 ? 0 : c);
+    total += c;
+  }
   return total;
 }

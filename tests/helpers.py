@@ -39,6 +39,10 @@ class Oracle:
             L.oracle_nb_entries.restype = C.c_uint64
             L.oracle_put_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
             L.oracle_put_many.restype = C.c_long
+            L.oracle_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint16,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            L.oracle_normalize_ascii.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+            L.oracle_normalize_ascii.restype = C.c_long
             cls._lib = L
         return cls._lib
 
@@ -74,11 +78,43 @@ class Oracle:
     def nb_entries(self, needle):
         return int(self.L.oracle_nb_entries(self.h, needle))
 
+    def batch(self, packed, offsets, idx=None, limit=10, find=True, nb=False, ntri=False, threads=None):
+        """oracle_find / oracle_nb_entries / distinct-trigram count for needles ``idx`` (all when
+        None) of a packed batch, on ``threads`` host threads (the oracle is read-only once built).
+        Returns a dict with rows uint32[n, limit, 3] + counts, nb uint64[n], ntri uint32[n]."""
+        n = len(offsets) - 1 if idx is None else len(idx)
+        threads = threads or min(os.cpu_count() or 1, 64)
+        packed = np.ascontiguousarray(packed)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        idx_a = None if idx is None else np.ascontiguousarray(idx, dtype=np.uint32)
+        out = {}
+        rows = counts = nb_a = nt_a = None
+        if find:
+            rows = np.zeros((n, max(limit, 1), 3), dtype=np.uint32)
+            counts = np.zeros(n, dtype=np.uint32)
+            out["rows"], out["counts"] = rows, counts
+        if nb:
+            nb_a = out["nb"] = np.zeros(n, dtype=np.uint64)
+        if ntri:
+            nt_a = out["ntri"] = np.zeros(n, dtype=np.uint32)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        self.L.oracle_batch(self.h, packed.ctypes.data, offsets.ctypes.data, ptr(idx_a), n, limit,
+                            ptr(rows), ptr(counts), ptr(nb_a), ptr(nt_a), threads)
+        return out
+
     @classmethod
     def tokenise(cls, needle):
         out = (C.c_uint16 * (len(needle) + 1))()
         n = cls.lib().oracle_tokenise(needle, out)
         return list(out[:n])
+
+    @classmethod
+    def normalize_ascii(cls, raw):
+        """oracle/normalize_oracle.c: Blurrily::Map#normalize_string restated from the Ruby text
+        (lib/blurrily/map.rb:40-47), ASCII input only (None for input with a byte >= 0x80)."""
+        out = C.create_string_buffer(len(raw) + 1)
+        n = cls.lib().oracle_normalize_ascii(raw, len(raw), out)
+        return None if n < 0 else out.raw[:n]
 
 
 class Reference:
@@ -99,7 +135,7 @@ class Reference:
             S.ref_save.argtypes = [C.c_void_p, C.c_char_p]
             S.ref_stats.argtypes = [C.c_void_p, C.c_void_p]
             S.ref_tokenise.argtypes = [C.c_char_p, C.c_void_p]
-            S.ref_find_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint16, C.c_void_p]
+            S.ref_find_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint16, C.c_void_p, C.c_void_p]
             S.ref_find_many.restype = C.c_long
             cls._shim = S
         return cls._shim

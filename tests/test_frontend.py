@@ -234,3 +234,32 @@ def test_server_saves_when_quitting(running_server):
     assert proc.wait(30) == 0
     assert (directory / "words.trigrams").exists()
     assert Map.load(directory / "words.trigrams").stats()["references"] == 1
+
+
+def test_server_saves_on_usr1_through_the_worker_thread(running_server):
+    """server.rb:26 (USR1 saves).  Saves run on the worker thread that owns the maps, queued behind
+    the commands already accepted, so the file holds every acknowledged PUT."""
+    port, proc, directory = running_server
+    f = socket.create_connection(("127.0.0.1", port)).makefile("rwb")
+    f.write(b"".join(b"PUT\twords\tword%d\t%d\n" % (i, i) for i in range(1, 201)))
+    f.flush()
+    assert [f.readline() for _ in range(200)] == [b"OK\n"] * 200
+    proc.send_signal(signal.SIGUSR1)
+    deadline = time.time() + 30
+    while not (directory / "words.trigrams").exists():
+        assert time.time() < deadline
+        time.sleep(0.05)
+    time.sleep(0.2)                                             # (the rename is atomic; let the save finish)
+    assert Map.load(directory / "words.trigrams").stats()["references"] == 200
+    f.write(b"PUT\twords\tlater\t999\n")                        # still serving
+    f.flush()
+    assert f.readline() == b"OK\n"
+
+
+def test_server_refuses_an_endless_line(running_server):
+    port, _, _ = running_server
+    s = socket.create_connection(("127.0.0.1", port))
+    s.sendall(b"FIND\twords\t" + b"a" * (80 * 1024))              # no newline
+    f = s.makefile("rb")
+    assert f.readline() == b"ERROR\tline too long\n"
+    assert f.readline() == b""                                  # and the connection is closed

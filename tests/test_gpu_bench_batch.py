@@ -1,0 +1,106 @@
+"""The call and the batch bench.py times, checked: blurrily_storage_find_batch_device on
+BASELINE.json configs[2] -- haystack seed 3 (8 423 769 strings), needle seed 3000, ONE batch of
+1 000 000 device-resident needles, limit 10, nb_entries requested -- with the inputs built by the
+same tools/workloads.py functions bench.py uses.
+
+  * every one of the 1 M needles: rows in the reference's total order (matches desc, weight asc,
+    reference asc -- storage.c:129-138 + the stable-sort tie order pinned by
+    spec/integration_spec.rb:37-42), no reference twice, 1 <= matches <= T, counts <= limit,
+    weight == strlen of the indexed string (storage.c:409), and d_nb_entries equal to the
+    oracle's nb_entries (storage.c:498-503) -- all 1 M of them;
+  * 1 200 sampled needles row for row against the oracle;
+  * the host-buffer entry point on a slice of the same batch gives the same rows.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import workloads as W
+from blurrily_amd import RawMap, _native
+from helpers import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _order_ok(rows, counts, limit):
+    """Vectorised: consecutive rows ascend strictly in (-matches, weight, reference)."""
+    r = rows.astype(np.int64)
+    ok = True
+    for k in range(limit - 1):
+        valid = counts > k + 1
+        a, b = r[valid, k], r[valid, k + 1]
+        lt = (a[:, 1] > b[:, 1]) | ((a[:, 1] == b[:, 1]) & ((a[:, 2] < b[:, 2]) |
+                                                            ((a[:, 2] == b[:, 2]) & (a[:, 0] < b[:, 0]))))
+        ok &= bool(lt.all())
+    return ok
+
+
+@pytest.mark.parametrize("name,n_sample", [("geonames", 1200), ("words", 3000), ("skewed", 300)])
+def test_the_benched_call_on_the_benched_batch(name, n_sample):
+    import torch
+    spec = W.BENCH_WORKLOADS[name]
+    limit = spec["limit"]
+    hay, off = W.bench_haystack(name)
+    n = len(off) - 1
+    qp, qo = W.bench_needles(hay, off, name)
+    n_q = len(qo) - 1
+    assert n == spec["n"] and n_q == spec["queries"]
+
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    m.sync_device()
+    dev = torch.device("cuda", 0)
+    d_packed = torch.from_numpy(qp).to(dev)
+    d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
+    d_results = torch.full((n_q, limit, 3), -1, dtype=torch.int32, device=dev)
+    d_counts = torch.full((n_q,), -1, dtype=torch.int32, device=dev)
+    d_nb = torch.full((n_q,), -1, dtype=torch.int32, device=dev)
+    lib = _native.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    res = lib.blurrily_storage_find_batch_device(m.handle, d_packed.data_ptr(), int(qo[-1]), d_off.data_ptr(), n_q,
+                                                 limit, d_results.data_ptr(), d_counts.data_ptr(), d_nb.data_ptr(),
+                                                 stream)
+    assert res == 0, C.get_errno()
+    torch.cuda.synchronize()
+    rows = d_results.cpu().numpy().view(np.uint32)
+    counts = d_counts.cpu().numpy().view(np.uint32).astype(np.int64)
+    nb = d_nb.cpu().numpy().view(np.uint32).astype(np.uint64)
+
+    o = Oracle()
+    o.put_many(hay, off)
+    every = o.batch(qp, qo, find=False, nb=True, ntri=True)
+
+    # ---- all needles ---------------------------------------------------------------------
+    assert np.array_equal(nb, np.minimum(every["nb"], 0xFFFFFFFF)), "d_nb_entries != oracle nb_entries"
+    assert counts.min() >= 1 and counts.max() <= limit           # every needle is an edited haystack string
+    assert _order_ok(rows, counts, limit)
+    live = np.arange(limit)[None, :] < counts[:, None]
+    T = every["ntri"].astype(np.int64)
+    matches = rows[:, :, 1].astype(np.int64)
+    assert ((matches >= 1) | ~live).all() and ((matches <= T[:, None]) | ~live).all()
+    refs = rows[:, :, 0].astype(np.int64)
+    assert ((refs >= 1) & (refs <= n) | ~live).all()
+    srt = np.sort(np.where(live, refs, -np.arange(1, limit + 1)[None, :]), axis=1)   # distinct fillers
+    assert (srt[:, 1:] != srt[:, :-1]).all(), "a reference twice in one needle's rows"
+    hay_len = (off[1:] - off[:-1]).astype(np.int64)               # weight 0 -> strlen (storage.c:409)
+    assert (np.where(live, rows[:, :, 2].astype(np.int64) - hay_len[np.clip(refs - 1, 0, n - 1)], 0) == 0).all()
+
+    # ---- a sample, row for row against the oracle ------------------------------------------
+    rng = np.random.default_rng(2024)
+    idx = np.sort(rng.choice(n_q, size=n_sample, replace=False)).astype(np.uint32)
+    want = o.batch(qp, qo, idx=idx, limit=limit)
+    assert np.array_equal(counts[idx], want["counts"])
+    for k, q in enumerate(idx):
+        c = int(counts[q])
+        assert np.array_equal(rows[q, :c], want["rows"][k, :c]), (int(q), rows[q, :c].tolist(),
+                                                                  want["rows"][k, :c].tolist())
+
+    # ---- the host-buffer entry point agrees on a slice of the batch --------------------------
+    lo, hi = n_q // 2, n_q // 2 + 5000
+    sub_off = (qo[lo:hi + 1] - qo[lo]).astype(np.uint64)
+    sub = qp[int(qo[lo]):int(qo[hi])]
+    h_rows, h_counts = m.find_batch_packed(sub, sub_off, limit)
+    assert np.array_equal(h_counts.astype(np.int64), counts[lo:hi])
+    live_s = np.arange(limit)[None, :] < counts[lo:hi, None]
+    assert np.array_equal(np.where(live_s[:, :, None], h_rows, 0), np.where(live_s[:, :, None], rows[lo:hi], 0))

@@ -1,6 +1,7 @@
-"""GPU parity of the device-side needle normaliser against the host mirror of
-Blurrily::Map#normalize_string (lib/blurrily/map.rb:40-47; pinned on the CPU side by
-tests/test_normalize.py against spec/blurrily/map_spec.rb's vectors)."""
+"""GPU parity of the device-side needle normaliser against
+oracle/normalize_oracle.c -- Blurrily::Map#normalize_string restated in C from the Ruby text
+(lib/blurrily/map.rb:40-47), independent of both the kernel and the product's Python mirror
+(which tests/test_normalize.py checks against the same oracle and the spec's vectors)."""
 import ctypes as C
 
 import numpy as np
@@ -9,24 +10,14 @@ import pytest
 import workloads as W
 from blurrily_amd import Map, RawMap, _native, normalize_string
 from blurrily_amd.map import _pack
+from helpers import Oracle
+from test_normalize import EDGE_NEEDLES, random_ascii_needles
 
 pytestmark = pytest.mark.gpu
-
-ALPHABET = (list(b"abcdefghijklmnopqrstuvwxyz") * 6 + list(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ") * 2 + list(b"      ")
-            + list(b"0123456789-_'.,;:!?@#()[]/\\\"") + [9, 10, 10, 11, 12, 13, 0, 127, 1, 31])
-
 
 def _seen_by_c(b):
     """What the C side reads of a needle: the bytes up to the first NUL."""
     return b.split(b"\0", 1)[0]
-
-
-def _random_ascii(rng, n):
-    out = []
-    for _ in range(n):
-        ln = int(rng.integers(0, 40))
-        out.append(bytes(rng.choice(ALPHABET, size=ln).tolist()))
-    return out
 
 
 class _Hip:
@@ -78,22 +69,19 @@ def _device_normalise(needles):
 
 
 def test_spec_vectors_and_edges():
-    needles = [b"London", b"  New   York ", b"Port-au-Prince", b"", b"   ", b"\t\n", b"A", b"@#%", b"abc\ndef",
-               b"abc\n@@ x", b"ab\ncd\0ef", b"\0abc", b"abc\0\0", b"Abc \0", b"x\ry", b"UPPER lower  MiXeD",
-               b"tab\tsep", b"trailing  ", b"  leading", b"a--b", b"ab\n", b"\nab", b"a\x7fb", b"plain line\nJUNK!!\n"]
+    needles = list(EDGE_NEEDLES)
     got, got_inplace, flags = _device_normalise(needles)
     for nd, g, gi in zip(needles, got, got_inplace):
-        want = _seen_by_c(normalize_string(nd.decode("latin1")).encode("latin1"))
+        want = _seen_by_c(Oracle.normalize_ascii(nd))
         assert g == want, (nd, g, want)
         assert gi == want, (nd, gi, want)
     assert not flags.any()
 
 
-def test_random_ascii_needles_match_the_host_mirror():
-    rng = np.random.default_rng(77)
-    needles = _random_ascii(rng, 20000)
+def test_random_ascii_needles_match_the_oracle_normaliser():
+    needles = random_ascii_needles(77, 20000)
     got, got_inplace, flags = _device_normalise(needles)
-    want = [_seen_by_c(normalize_string(nd.decode("latin1")).encode("latin1")) for nd in needles]
+    want = [_seen_by_c(Oracle.normalize_ascii(nd)) for nd in needles]
     assert got == want
     assert got_inplace == want
     assert not flags.any()

@@ -101,15 +101,106 @@ def test_command_processor_vector():
     assert m.find("great") == [[12, 6, 12], [13, 5, 16]]
 
 
-def test_put_find_delete_cycle():
-    """spec/blurrily/map_spec.rb:377-384 (smaller count: every step rebuilds the device index)."""
-    m = Map()
-    for index in range(64):
+# ---- the reference's stress checks (spec/blurrily/map_spec.rb:355-403), at its own 1 024 iterations,
+# ---- with the oracle replaying every step and the device image served by delta + tombstones --------
+STRESS_COUNT = 1024          # map_spec.rb:361 "enough cycles to force reallocations"
+
+
+def _stress_pair():
+    from helpers import Oracle
+    return Map(), Oracle()
+
+
+def test_stress_puts():
+    """map_spec.rb:363-367."""
+    m, o = _stress_pair()
+    for index in range(STRESS_COUNT):
+        assert m.put("Port-au-Prince", index) == o.put(b"port au prince", index, 0)
+    assert m.stats() == o.stats() and m.stats()["references"] == STRESS_COUNT
+    assert m.find("Port-au-Prince") == o.find(b"port au prince", 10) != []
+    assert m.find("Port-au-Prince", 1024) == o.find(b"port au prince", 1024)      # all of them, in order
+
+
+def test_stress_put_delete_find():
+    """map_spec.rb:369-376."""
+    m, o = _stress_pair()
+    for index in range(STRESS_COUNT):
         m.put("Port-au-Prince", index)
+        o.put(b"port au prince", index, 0)
+        assert m.delete(index) == o.delete(index)
+        assert m.stats() == {"references": 0, "trigrams": 0}
+        assert m.find("Port-au-Prince") == []
+    assert m.device_info()["base_builds"] == 1            # served by the mutation log, not by rebuilds
+
+
+def test_stress_put_find_delete():
+    """map_spec.rb:377-384."""
+    m, o = _stress_pair()
+    for index in range(STRESS_COUNT):
+        m.put("Port-au-Prince", index)
+        o.put(b"port au prince", index, 0)
         assert m.stats()["references"] == 1
+        rows = m.find("Port-au-Prince")
+        assert rows == o.find(b"port au prince", 10) and rows[0][0] == index
+        m.delete(index)
+        o.delete(index)
+    info = m.device_info()
+    assert info["base_builds"] == 1 and info["n_tombstones"] == 1      # only reference 0 ever reached the base image
+
+
+def test_stress_puts_then_many_deletes():
+    """map_spec.rb:386-391, with a find between the deletes so that every tombstone is exercised."""
+    m, o = _stress_pair()
+    for index in range(STRESS_COUNT):
+        m.put("Port-au-Prince", index)
+        o.put(b"port au prince", index, 0)
+    assert m.find("Port-au-Prince", 5) == o.find(b"port au prince", 5)     # base image holds all 1 024
+    for index in range(STRESS_COUNT):
+        assert m.delete(index) == o.delete(index)
+        if index % 16 == 0 or index > STRESS_COUNT - 8:
+            assert m.find("Port-au-Prince", 20) == o.find(b"port au prince", 20)
+    assert m.stats() == {"references": 0, "trigrams": 0}
+    assert m.find("Port-au-Prince") == []
+    assert m.device_info()["base_builds"] == 1
+
+
+def test_stress_puts_reload_many_deletes(tmp_path):
+    """map_spec.rb:393-403."""
+    m, o = _stress_pair()
+    for index in range(STRESS_COUNT):
+        m.put("Port-au-Prince", index)
+        o.put(b"port au prince", index, 0)
+    path = str(tmp_path / "stress.trigrams")
+    m.save(path)
+    m = Map.load(path)
+    assert m.find("Port-au-Prince", 7) == o.find(b"port au prince", 7)
+    for index in range(STRESS_COUNT):
+        assert m.delete(index) == o.delete(index)
+        if index % 64 == 0:
+            assert m.find("Port-au-Prince", 7) == o.find(b"port au prince", 7)
+    assert m.stats() == {"references": 0, "trigrams": 0}
+    assert m.find("Port-au-Prince") == []
+    assert m.device_info()["base_builds"] == 1
+
+
+def test_stress_put_save_load_cycles(tmp_path):
+    """map_spec.rb:407-437 (100 iterations): cold loads, put/save/load/delete, put/save/load."""
+    path = str(tmp_path / "cycle.trigrams")
+    m = Map()
+    for index in range(100):
+        m.put("Port-au-Prince", index)
+        m.save(path)
+        m = Map.load(path)
+        assert m.stats()["references"] == index + 1
+    assert [r[0] for r in m.find("Port-au-Prince", 100)] == list(range(100))
+    m = Map()
+    for index in range(100):
+        m.put("Port-au-Prince", index)
+        m.save(path)
+        m = Map.load(path)
         assert m.find("Port-au-Prince")[0][0] == index
         m.delete(index)
-        assert m.find("Port-au-Prince") == []
+        assert m.stats()["references"] == 0 and m.find("Port-au-Prince") == []
 
 
 # ---- seeded random haystacks vs the oracle ------------------------------------------------

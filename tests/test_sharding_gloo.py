@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from blurrily_amd.sharding import shard_bounds
+from blurrily_amd.sharding import ResultBlock, block_bytes, shard_bounds
 
 
 def test_shard_bounds_cover_everything():
@@ -21,6 +21,16 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_result_block_is_one_buffer_of_fixed_stride():
+    """limit x 12 B + 4 B per needle, rows and counts views of one allocation."""
+    b = ResultBlock(7, 10)
+    assert b.buf.numel() * 4 == block_bytes(7, 10) == 7 * (10 * 12 + 4)
+    b.rows[6, 9, 2] = 77
+    b.counts[6] = 5
+    assert int(b.buf[7 * 30 - 1]) == 77 and int(b.buf[-1]) == 5
+    assert b.rows.data_ptr() == b.buf.data_ptr() and b.counts.data_ptr() == b.buf.data_ptr() + 7 * 120
 
 
 def _free_port():
@@ -46,17 +56,25 @@ def _worker(rank, world, port, n_needles, limit, out_path):
     q, qo = W.queries(hay, off, n_needles, 6)
     needles = W.unpack(q, qo)
 
-    def find_fn(batch, lim):                           # stand-in for the per-rank GPU batch
-        rows = torch.zeros((len(batch), lim, 3), dtype=torch.int32)
-        counts = torch.zeros((len(batch),), dtype=torch.int32)
+    calls = []
+    real_gather = dist.gather
+
+    def counting_gather(*a, **k):                      # the path has ONE exchange step
+        calls.append(1)
+        return real_gather(*a, **k)
+    dist.gather = counting_gather
+
+    def find_fn(batch, lim, rows, counts):             # stand-in for the per-rank GPU batch: fills the block in place
+        assert rows.shape == (len(batch), lim, 3) and counts.shape == (len(batch),)
         for i, nd in enumerate(batch):
             r = o.find(nd, lim)
             counts[i] = len(r)
             if r:
                 rows[i, :len(r)] = torch.tensor(r, dtype=torch.int64).to(torch.int32)
-        return rows, counts
 
     got = find_batch_sharded(dist, find_fn, needles, limit, rank, world)
+    dist.gather = real_gather
+    assert len(calls) == 1, calls
     if rank == 0:
         rows, counts = got
         ok = rows.shape[0] == n_needles

@@ -72,3 +72,33 @@ def unpack(packed, offsets):
 def count_trigrams(packed, offsets):
     """Sum of distinct-trigram counts over the needles."""
     return int(_synth().synth_count_trigrams(packed.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
+
+
+# ---- the inputs bench.py times (shared with tests/test_gpu_bench_batch.py, which checks that very
+# ---- call on those very inputs) ------------------------------------------------------------------
+BENCH_WORKLOADS = {
+    # name: haystack generator arguments, needles per rank, limit, the BASELINE.json config it is
+    "geonames": dict(kind="geonames", n=8423769, vocab=500000, hay_seed=3, queries=1_000_000, limit=10,
+                     label="configs[2]: synthetic Geonames-scale haystack, 1M batched needles"),
+    "words":    dict(kind="words", n=235886, hay_seed=1, queries=100_000, limit=10,
+                     label="configs[1]: 235k-word haystack, 100k batched needles"),
+    "skewed":   dict(kind="skewed", n=4_000_000, hay_seed=5, queries=100_000, limit=100,
+                     label="configs[4]: adversarial hot-trigram haystack, limit=100"),
+}
+
+
+def bench_haystack(name, scale=1.0):
+    """(packed, offsets) of the haystack bench.py indexes for `name` (refs are 1..n, weight 0)."""
+    spec = BENCH_WORKLOADS[name]
+    n = max(1000, int(spec["n"] * scale))
+    if spec["kind"] == "geonames":
+        return geonames(n, max(1000, int(spec["vocab"] * min(1.0, scale * 4))), spec["hay_seed"])
+    if spec["kind"] == "words":
+        return words(n, spec["hay_seed"])
+    return skewed(n, spec["hay_seed"])
+
+
+def bench_needles(hay, hay_off, name, scale=1.0, rank=0, world=1):
+    """This rank's shard of the step batch: world x n_q needles in contiguous shards, seeded per rank."""
+    n_q = max(100, int(BENCH_WORKLOADS[name]["queries"] * scale))
+    return queries(hay, hay_off, n_q, (3 if world == 1 else 4) * 1000 + rank)
