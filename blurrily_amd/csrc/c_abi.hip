@@ -210,6 +210,23 @@ int apply_tombstones(trigram_map m, hipStream_t stream) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Tunables of the window-major sweep (environment, read at every find call): BLURRILY_WSWEEP=0 turns it off;
+// BLURRILY_WS_CMIN (default 3, measured best) is the least number of counted matches a left-out slice must leave;
+// BLURRILY_WS_MIN_WINDOWS / BLURRILY_WS_MIN_NEEDLES / BLURRILY_WS_MIN_SLICE bound the haystacks and
+// batches it is used for.
+uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
+}
+bool     ws_enabled()     { return env_u32("BLURRILY_WSWEEP", 1) != 0; }
+uint32_t ws_cmin()        { return std::max(1u, env_u32("BLURRILY_WS_CMIN", 3)); }
+uint32_t ws_min_windows() { return env_u32("BLURRILY_WS_MIN_WINDOWS", 8); }
+uint32_t ws_min_needles() { return env_u32("BLURRILY_WS_MIN_NEEDLES", 16384); }
+// BLURRILY_WS_MIN_SLICE: least DeviceIndex::mean_hit_slice.  Measured on MI355X (tools/ws_probe.py): at
+// 7 000 (configs[4], hot-trigram haystack) the window-major sweep is 1.4x the needle-major one, at 1 300
+// (configs[2], Geonames scale) it is 0.77x -- its fixed cost per (needle, window) is not yet paid back.
+uint32_t ws_min_slice()   { return env_u32("BLURRILY_WS_MIN_SLICE", 3000); }
 constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for small host-buffer batches
 
 // Enqueue tokenise + find for n device-resident needles.
@@ -315,8 +332,34 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
     }
+    // Large batches over many windows: the window-major sweep (find_kernels.hip, wsweep_kernel).
+    // Phase 1 -- the needle-major kernel over the window pair of every needle's own length class --
+    // seeds the needles' states; one launch per window follows; keys become rows at the end.
+    const bool use_ws = ranges <= 1 && ws_enabled() && limit <= kWsMaxKeep && ix.n_windows >= ws_min_windows() &&
+                        n >= ws_min_needles() && ix.d_bm_id != nullptr && code_slots < 0xFFFFFFFFull &&
+                        ix.mean_hit_slice >= double(ws_min_slice());
+    if (use_ws) {
+      a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
+      a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
+      a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = ws_cmin();
+      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+      a.short_only = 1; a.own_only = 1;
+      if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+      a.own_only = 0;
+      for (uint32_t w = 0; w < ix.n_windows; ++w) {
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        if (launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), stream) < 0) return -1;
+      }
+      if (launch_finalize_rows(a, uint32_t(n), stream) < 0) return -1;
+      a.short_only = 0;
+      if (maybe_mid) {                               // 65..127 distinct trigrams: needle-major, all windows
+        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+      }
+    }
     // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
-    for (uint32_t base = 0; ranges <= 1 && base < limit; base += 1024) {
+    for (uint32_t base = 0; !use_ws && ranges <= 1 && base < limit; base += 1024) {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = base; a.keep = std::min<uint32_t>(1024, limit - base);
       a.pool_cap = find_pool_cap(a.keep);
@@ -358,8 +401,8 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
              uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, bool maybe_long,
              bool maybe_mid, hipStream_t stream) {
   if (m->collect_stats) {
-    if (!m->d_stats) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), kStatSlots * 8));
-    BLURRILY_HIP_TRY(hipMemsetAsync(m->d_stats, 0, kStatSlots * 8, stream));
+    if (!m->d_stats) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), kStatAllSlots * 8));
+    BLURRILY_HIP_TRY(hipMemsetAsync(m->d_stats, 0, kStatAllSlots * 8, stream));
   }
   if (apply_tombstones(m, stream) < 0) return -1;
   if (log_empty(m))
@@ -641,6 +684,16 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
 void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabled != 0; }
 
 void blurrily_storage_set_stats(trigram_map m, int enabled) { m->collect_stats = enabled != 0; }
+
+// debugging aid (tools/ws_probe.py): all counter slots, phase clocks of the window-major sweep included
+int blurrily_debug_find_stats16(trigram_map m, uint64_t* out16) {
+  std::memset(out16, 0, kStatAllSlots * 8);
+  if (!m->d_stats) return 0;
+  DeviceScope scope(m->dev.device);
+  BLURRILY_HIP_TRY(hipDeviceSynchronize());
+  BLURRILY_HIP_TRY(hipMemcpy(out16, m->d_stats, kStatAllSlots * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int blurrily_storage_find_stats(trigram_map m, uint64_t* out8) {
   std::memset(out8, 0, kStatSlots * 8);

@@ -20,6 +20,8 @@
 //     eight entries with the sentinel 0xFFFF (the one in-window rank no
 //     reference uses), so the kernel counts whole 16-byte groups without any
 //     range check; counter slot 0xFFFF is a scratch slot the scan ignores.
+//   * a slice with >= kDenseMin postings additionally exists as a bitmap over the window's ranks
+//     (bm_id[w * kNumCodes + t] -> bitmaps[id * kBitmapWords ..]); see find_kernels.hip, wsweep_kernel.
 //   * code_total[t] = used[t] of the reference's bucket t (storage.c:501), for
 //     the matched-entries metric.
 //   * win_max_tri[w]: the largest number of postings (= distinct trigrams) any one
@@ -47,6 +49,15 @@ constexpr uint32_t kWindowSize  = 1u << kWindowBits;    // counter slots per win
 constexpr uint32_t kWindowRanks = kWindowSize - 1;      // ranks per window; slot 0xFFFF = padding sentinel
 constexpr uint16_t kPadRank     = uint16_t(kWindowSize - 1);
 constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byte over-reads)
+// A (window, code) slice with at least this many postings also exists as a BITMAP of the window
+// (kWindowSize bits = 8 KiB; bit r set iff in-window rank r holds the code): the window-major sweep
+// leaves such slices out of the count and asks the bitmap about the few ranks that matter instead.
+#ifndef BLURRILY_DENSE_MIN
+#define BLURRILY_DENSE_MIN 1024
+#endif
+constexpr uint32_t kDenseMin     = BLURRILY_DENSE_MIN;
+constexpr uint32_t kBitmapWords  = kWindowSize / 32;    // u32 words per bitmap
+constexpr uint32_t kNoBitmap     = 0xFFFFFFFFu;
 
 struct DeviceIndex {
   int       device        = -1;
@@ -66,6 +77,14 @@ struct DeviceIndex {
   uint32_t* d_win_max_tri    = nullptr;   // [n_windows] most postings any one reference of the window has
   uint32_t* d_start_win      = nullptr;   // [256] window holding the first rank whose weight is >= the index
   uint32_t* d_tomb           = nullptr;   // [(n_refs+31)/32] bit r: rank r was deleted after the build
+  uint32_t* d_bm_id          = nullptr;   // [n_windows * kNumCodes] bitmap number of a dense slice, else kNoBitmap
+  uint32_t* d_bitmaps        = nullptr;   // [n_bitmaps * kBitmapWords]
+  uint32_t  n_bitmaps        = 0;
+  // postings a needle's trigram finds in one window, on average, when needle trigrams are distributed
+  // like the haystack's postings: (sum of used[t]^2 / sum of used[t]) / n_windows.  The window-major
+  // sweep pays a fixed price per (needle, window) and saves in proportion to the postings it leaves
+  // out, so it is taken only where slices are big (c_abi.hip).
+  double    mean_hit_slice   = 0.0;
   // host copies for mapping a reference to its rank (deletes after the build)
   std::vector<uint32_t> h_sorted_ref;     // references ascending
   std::vector<uint32_t> h_rank_of_pos;    // rank of h_sorted_ref[i]

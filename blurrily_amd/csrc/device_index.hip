@@ -85,6 +85,8 @@ void device_index_free(DeviceIndex* ix) {
   if (ix->d_win_max_tri)    (void)hipFree(ix->d_win_max_tri);
   if (ix->d_start_win)      (void)hipFree(ix->d_start_win);
   if (ix->d_tomb)           (void)hipFree(ix->d_tomb);
+  if (ix->d_bm_id)          (void)hipFree(ix->d_bm_id);
+  if (ix->d_bitmaps)        (void)hipFree(ix->d_bitmaps);
   *ix = DeviceIndex();
 }
 
@@ -224,9 +226,13 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   if (failed.load()) { errno = EPROTO; return -1; }
   stage("rank postings");
 
-  // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum
+  // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum; dense slices get a
+  // bitmap number (in slice order: the image does not depend on thread timing)
   uint64_t n_slots = 0;
+  std::vector<uint32_t> bm_id(n_slices, kNoBitmap);
+  uint32_t n_bitmaps = 0;
   for (uint64_t i = 0; i < n_slices; ++i) {
+    if (slice_off[i + 1] >= kDenseMin) bm_id[i] = n_bitmaps++;
     const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
     n_slots += len;
     if (n_slots > 0xFFFF0000ull) { errno = EPROTO; return -1; }
@@ -242,14 +248,17 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   // in (bank, rank) order round-robin over the 16 instruction-halves, so one half sees each
   // bank -- and each counter word -- about once.
   std::vector<uint16_t> ent(n_slots + kEntPad, kPadRank);
+  std::vector<uint32_t> bitmaps(size_t(n_bitmaps) * kBitmapWords, 0u);
   parallel_codes([&](uint32_t t) {
     const uint32_t used = code_total[t];
     if (!used) return;
     const uint32_t* rk = rank.data() + bucket_base[t];
     std::vector<uint32_t> fill(n_win, 0);
     for (uint32_t j = 0; j < used; ++j) {
-      const uint32_t w = rk[j] / kWindowRanks;
-      ent[slice_off[uint64_t(w) * kNumCodes + t] + fill[w]++] = uint16_t(rk[j] % kWindowRanks);
+      const uint32_t w = rk[j] / kWindowRanks, r = rk[j] % kWindowRanks;
+      ent[slice_off[uint64_t(w) * kNumCodes + t] + fill[w]++] = uint16_t(r);
+      const uint32_t id = bm_id[uint64_t(w) * kNumCodes + t];         // (a slice belongs to one worker: no race)
+      if (id != kNoBitmap) bitmaps[size_t(id) * kBitmapWords + (r >> 5)] |= 1u << (r & 31);
     }
     std::vector<uint16_t> tmp;
     for (uint32_t w = 0; w < n_win; ++w) {
@@ -310,6 +319,12 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   DeviceIndex ix;
   ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz; ix.n_slots = n_slots;
   ix.built_from = host.generation();
+  ix.n_bitmaps = n_bitmaps;
+  {
+    double sq = 0.0;
+    for (uint32_t t = 0; t < kNumCodes; ++t) sq += double(code_total[t]) * double(code_total[t]);
+    ix.mean_hit_slice = nnz ? sq / double(nnz) / double(n_win) : 0.0;
+  }
   while (ix.nib_windows + 1 < n_win && win_max_tri[ix.nib_windows] <= 15 && win_max_tri[ix.nib_windows + 1] <= 15)
     ix.nib_windows += 2;
   auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {   // v may be a temporary
@@ -323,7 +338,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   if (up(&ix.d_ref_of_rank, ref_of_rank, 1) || up(&ix.d_weight_of_rank, weight_of_rank, 1) ||
       up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
       up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1) ||
-      up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1)) {
+      up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1) ||
+      up(&ix.d_bm_id, bm_id, 1) || up(&ix.d_bitmaps, bitmaps, 1)) {
     const int e = errno;
     device_index_free(&ix);
     errno = e;

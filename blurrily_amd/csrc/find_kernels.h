@@ -44,6 +44,12 @@ struct FindArgs {
   const uint32_t* win_max_tri; // [n_windows] match-count bound per window
   uint32_t        nib_windows; // windows [0, nib_windows): no reference with more than 15 trigrams (4-bit counters suffice)
   const uint32_t* tomb;        // bit r set: rank r was deleted after the image was built (nullptr: none)
+  // window-major sweep (wsweep_kernel): bitmaps of the dense slices, and how the work is split
+  const uint32_t* bm_id;       // [n_windows * kNumCodes] bitmap number of a dense slice, else kNoBitmap
+  const uint32_t* bitmaps;     // [n_bitmaps * kBitmapWords]
+  uint32_t        own_only;    // find_kernel: sweep only the window pair of the needle's own length class and leave
+                               // the best keys (not rows) in `results` as the needle's state for wsweep_kernel
+  uint32_t        cmin;        // wsweep: a skipped slice must leave at least this many matches to count (>= 1)
   const uint32_t* work_list;   // nullptr: slots are needle ids, long needles skipped
   const uint32_t* n_work_dev;  // when set, the number of slots is read from the device
   uint32_t        n_work;
@@ -75,7 +81,12 @@ enum : uint32_t {
   kStatTasks          = 3,   // needles (or needle ranges) swept
   kStatCompactions    = 4,   // candidate-pool compactions
   kStatResweeps       = 5,   // windows swept again after a pool overflow
-  kStatSlots          = 8,
+  kStatBitmapWords    = 6,   // (reserved)
+  kStatProbes         = 7,   // bitmap words read for candidates of the window-major sweep (x4 = bytes)
+  kStatSlots          = 8,   // what blurrily_storage_find_stats reports
+  kStatWsClocks       = 8,   // + 0..5: shader clocks of wave 0 per phase of wsweep_kernel, summed over workgroups
+                             //   (filter, task set-up, count, scan, probe, select + write-back); debugging aid
+  kStatAllSlots       = 16,
 };
 
 uint32_t find_pool_cap(uint32_t keep);
@@ -87,6 +98,12 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
                      hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
+// Window-major sweep of window `w` over needles [0, n) (those with <= 64 distinct trigrams whose state
+// find_kernel left with own_only set); a.queue must be a zeroed word of its own.
+int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hipStream_t stream);
+// Turn the needles' states (keys) into result rows, in place.
+int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream);
+constexpr uint32_t kWsMaxKeep = 128;   // largest limit the window-major sweep serves
 // Merge, per needle, two result lists that are each in result order (base image and delta image
 // hold disjoint references) into the first `limit` rows of `out`.
 int launch_merge_rows(const trigram_match_t* a_rows, const uint32_t* a_counts, const trigram_match_t* b_rows,

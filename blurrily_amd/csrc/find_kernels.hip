@@ -1161,8 +1161,12 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     const uint32_t q = A.work_list ? A.work_list[item] : item;
     // (ranges start on even windows: the 4-bit sweep takes windows in pairs)
     const uint32_t n_pairs = (A.n_windows + 1) / 2;
-    const uint32_t w0 = RANGED ? 2 * uint32_t(uint64_t(n_pairs) * range / R) : 0u;
-    const uint32_t w1 = RANGED ? min(A.n_windows, 2 * uint32_t(uint64_t(n_pairs) * (range + 1) / R)) : A.n_windows;
+    // (own_only: the window pair of the needle's own length class -- phase 1 of the window-major sweep)
+    const bool own_only = !RANGED && A.own_only;
+    const uint32_t own0 = own_only ? (A.q_start[q] & ~1u) : 0u;
+    const uint32_t w0 = RANGED ? 2 * uint32_t(uint64_t(n_pairs) * range / R) : own0;
+    const uint32_t w1 = RANGED ? min(A.n_windows, 2 * uint32_t(uint64_t(n_pairs) * (range + 1) / R))
+                               : own_only ? min(A.n_windows, own0 + 2) : A.n_windows;
     Needle nd;
     nd.T = A.q_ntri[q];
     if (!A.work_list && nd.T > (SHORT ? 64u : 127u)) { // longer needles: the mid / wide-counter launches
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     // -- worth it only when there are enough windows for the early threshold to pay back the
     // ties it forfeits (a window behind the threshold's rank needs one match more)
     const uint32_t qs = A.q_start[q];
-    const uint32_t ws = (w1 - w0 >= 8 && qs >= w0 && qs < w1) ? qs : w0;
+    const uint32_t ws = ((w1 - w0 >= 8 || own_only) && qs >= w0 && qs < w1) ? qs : w0;
     // results after this key only (later passes of a limit larger than the pool)
     nd.has_floor = A.pass_base != 0;
 
@@ -1241,6 +1245,17 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
       // latency mode: leave this range's best keys for merge_parts_kernel
       for (uint32_t i = tid; i < nres; i += NT) A.part_keys[size_t(slot) * A.keep + i] = pool[i];
       if (tid == 0) A.part_count[slot] = nres;
+      __syncthreads();
+      continue;
+    }
+    if (own_only) {
+      // the needle's state for wsweep_kernel: its best keys so far, two words each, where its rows will be
+      uint32_t* st = reinterpret_cast<uint32_t*>(A.results + size_t(q) * A.limit);
+      for (uint32_t i = tid; i < nres; i += NT) {
+        const unsigned long long key = pool[i];
+        st[2 * i] = uint32_t(key); st[2 * i + 1] = uint32_t(key >> 32);
+      }
+      if (tid == 0) A.counts[q] = nres;
       __syncthreads();
       continue;
     }
@@ -1379,6 +1394,563 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
   out_counts[q] = k;
 }
 
+// ============================================================ window-major sweep ============
+// The needle-major sweep above streams, for every needle, every posting of every one of its
+// trigrams: at Geonames scale 1.8 M postings per needle, 3.6 MB from HBM, most of them from the few
+// DENSE slices of the needle (a common trigram holds several per cent of a window's references).
+// Once a needle has a threshold -- `need` matches to enter its top `keep` -- those slices need not
+// be counted at all (the classic MaxScore argument, exact here):
+//
+//   leave out the L largest dense slices of the needle in this window, L <= need - cmin.  A
+//   reference with m >= need matches has at least need - L >= cmin >= 1 of them among the slices
+//   that ARE counted ("cold" count), so the scan finds it with the lower threshold need - L; for
+//   each such candidate the L left-out slices are consulted through their BITMAPS (one bit each,
+//   device_index.h), which gives its exact match count, and the usual key test admits it or not.
+//
+// That touches 10-25 % of the postings.  The bitmap probes are random 4-byte reads, affordable
+// only from L2, so the sweep runs WINDOW-MAJOR: one launch per window, every workgroup of the chip
+// working on the same window for different needles, the window's slice table, postings and bitmaps
+// (a few MB) resident in every XCD's L2 and read from HBM once per launch.  A needle's state -- its
+// best keys so far, hence its threshold -- lives in global memory between launches (in the needle's
+// own result rows, two words per key); phase 1 (find_kernel with own_only) seeds it from the
+// window pair of the needle's own length class, where its best matches live; finalize_rows_kernel
+// turns keys into rows.
+//
+// One task = (needle, window), run by a workgroup of 4 waves with 32 KiB of counters -- four
+// workgroups per CU: 4-bit counters for the whole window when a cold count cannot exceed 15 (nearly
+// always: the cold slices are few), else byte counters over the two halves of the window in turn.
+constexpr int      kWsNT    = 256;
+constexpr uint32_t kWsNW    = kWsNT / 64;
+constexpr uint32_t kWsCand  = 512;             // candidate list (rank | cold << 16): two per thread
+constexpr uint32_t kWsPool  = 256;             // candidate pool, >= 2 * kWsMaxKeep
+constexpr uint32_t kWsCntWords = kWindowSize / 8;   // 8192 words = 32 KiB: 65 536 nibbles or 32 768 bytes
+static_assert(kWsPool >= 2 * kWsMaxKeep && kWsPool <= uint32_t(kWsNT), "compact_pool's rank sort needs pool <= threads");
+static_assert(kWsCand == 2 * kWsNT, "the probe phase gives every thread two candidates");
+
+struct WsControl {
+  Control  c;
+  uint32_t n_cand;
+  uint32_t cand_ov;           // the candidate list overflowed in this pass
+  uint32_t n_tasks;
+  uint32_t chunk;
+};
+
+__device__ __forceinline__ unsigned long long ws_load_key(const FindArgs& A, uint32_t q, uint32_t i) {
+  const uint32_t* st = reinterpret_cast<const uint32_t*>(A.results + size_t(q) * A.limit);
+  return (static_cast<unsigned long long>(st[2 * i + 1]) << 32) | st[2 * i];
+}
+
+// one posting into the single-window 4-bit layout: rank r -> word r >> 3, nibble r & 7
+__device__ __forceinline__ void ws_bump_nib(uint32_t* cnt32, uint32_t r) {
+  __hip_atomic_fetch_add(&cnt32[r >> 3], 1u << ((r << 2) & 28u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// one posting into the half-window byte layout: rank r of half `h` -> byte r & 0x7FFF; a posting of the
+// other half goes to a dump word behind the counters
+__device__ __forceinline__ void ws_bump_byte(uint32_t* cnt32, uint32_t r, uint32_t h) {
+  const uint32_t word = (r >> 15) == h ? (r & 0x7FFFu) >> 2 : kWsCntWords;
+  __hip_atomic_fetch_add(&cnt32[word], 1u << ((r << 3) & 24u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool WIDE>
+__device__ __forceinline__ void ws_bump8(uint32_t* cnt32, const uint4 v, uint32_t h) {
+  if (!group_live(v)) return;
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (WIDE) { ws_bump_byte(cnt32, d[j] & 0xFFFFu, h); ws_bump_byte(cnt32, d[j] >> 16, h); }
+    else      { ws_bump_nib(cnt32, d[j] & 0xFFFFu);     ws_bump_nib(cnt32, d[j] >> 16); }
+  }
+}
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load
+// and store in flight (s_waitcnt vmcnt(0)), which would turn each of the kernel's barriers into a full
+// memory round trip and defeat the prefetches that are meant to travel across them; wsweep_kernel
+// exchanges data between its waves through LDS only.
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// compact_pool for wsweep_kernel (pool <= 256 keys = threads).  The first `n_sorted` keys are in order
+// (the needle's state, or what an earlier compaction left) and only the few keys admitted since then
+// follow them, so a key finds its place by MERGING: a sorted key is its index plus the new keys below it,
+// a new key is a binary search over the sorted ones plus the new keys below it -- a handful of steps
+// instead of one comparison per key of the pool (limit 100: ~100 per thread).  Keys are distinct.
+__device__ __forceinline__ void ws_compact_pool(unsigned long long* pool, Control* ctl, uint32_t keep, uint32_t n_sorted) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = min(ctl->pool_n, kWsPool);
+  n_sorted = min(n_sorted, n);
+  const unsigned long long mine = tid < n ? pool[tid] : kKeyInf;
+  uint32_t below = 0;
+  if (tid < n) {
+    for (uint32_t j = n_sorted; j < n; ++j) below += pool[j] < mine;    // same address in every lane: a broadcast
+    if (tid < n_sorted) {
+      below += tid;
+    } else {
+      uint32_t lo = 0, hi = n_sorted;                                   // first sorted key not below `mine`
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pool[mid] < mine) lo = mid + 1; else hi = mid;
+      }
+      below += lo;
+    }
+  }
+  ws_barrier();
+  if (tid < n && below < keep) pool[below] = mine;
+  ws_barrier();
+  if (tid == 0) {
+    ctl->pool_n = min(n, keep);
+    ctl->overflow = 0;
+    if (n >= keep && keep > 0) ctl->thr = pool[keep - 1];
+  }
+  ws_barrier();
+}
+
+// What the scans need to know about the two counter layouts of wsweep_kernel.
+//   WIDE = false: 4-bit counters, the whole window: vector i holds in-window ranks [32 i, 32 i + 32)
+//   WIDE = true : byte counters of half h of the window: vector i holds ranks [32768 h + 16 i, ... + 16)
+template <bool WIDE> struct WsLayout {
+  static constexpr uint32_t kRanksPerVec = WIDE ? 16 : 32, kBits = WIDE ? 8 : 4, kPerWord = WIDE ? 4 : 8;
+  static constexpr uint32_t kLastVec = kWsCntWords / 4 - 1;
+  uint32_t bias; bool low; uint32_t lo_r, nv; bool pad_here;
+  uint32_t pre;               // a counter >= need has one of these bits set (need >= 2^k: bits k.. of its field)
+  __device__ __forceinline__ WsLayout(uint32_t need, uint32_t h, uint32_t wlen) {
+    const uint32_t top = 31u - __clz(max(need, 1u));       // floor(log2(need))
+    pre = (WIDE ? 0x01010101u * ((0xFFu << top) & 0xFFu) : 0x11111111u * ((0xFu << top) & 0xFu));
+    if (WIDE) {
+      bias = (0x80u - min(need, 0x7Fu)) * 0x01010101u; low = false;
+      lo_r = h * 32768u;
+      const uint32_t span = wlen > lo_r ? min(32768u, wlen - lo_r) : 0u;
+      nv = (span + 15) / 16;
+      pad_here = h == 1;                                   // slot 0xFFFF: last byte of half 1
+    } else {
+      low = need <= 8;                                     // counter >= need, c = counter, lo = c & 7:
+      bias = (low ? 8 - need : 16 - need) * 0x11111111u;   //   need <= 8: c >= 8 or lo + (8 - need) >= 8
+      lo_r = 0; nv = (wlen + 31) / 32; pad_here = true;    //   need >  8: c >= 8 and lo + (16 - need) >= 8
+    }
+  }
+  // one bit per counter that reached `need`, at the top bit of its field
+  __device__ __forceinline__ uint32_t hits(uint32_t d) const {
+    if (WIDE) return (d + bias) & 0x80808080u;
+    const uint32_t t = (d & 0x77777777u) + bias;
+    return (low ? (t | d) : (t & d)) & 0x88888888u;
+  }
+  __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t i) const {
+    if (pad_here && i == kLastVec) v.w &= WIDE ? 0x00FFFFFFu : 0x0FFFFFFFu;    // slot 0xFFFF counts padding
+    return v;
+  }
+  __device__ __forceinline__ uint32_t rank16(uint32_t i, uint32_t j, uint32_t bit) const {
+    return lo_r + i * kRanksPerVec + j * kPerWord + bit / kBits;
+  }
+  __device__ __forceinline__ uint32_t count(uint32_t d, uint32_t bit) const {
+    return (d >> (bit / kBits * kBits)) & ((1u << kBits) - 1u);
+  }
+};
+
+// candidate (in-window rank, exact match count) -> key -> pool
+__device__ __forceinline__ void ws_admit(const FindArgs& A, Control* ctl, unsigned long long* pool, unsigned long long thr,
+                                         uint32_t T, uint32_t wbase, uint32_t r16, uint32_t total) {
+  const uint32_t rank = wbase + r16;
+  const unsigned long long key = (static_cast<unsigned long long>(T - total) << 32) | rank;
+  bool pass = key <= thr;
+  if (A.tomb) pass = pass && ((A.tomb[rank >> 5] >> (rank & 31)) & 1u) == 0;
+  if (pass) {
+    const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
+    if (at < kWsPool) pool[at] = key; else ctl->overflow = 1;
+  }
+}
+
+// Fast scan: counters that reach `need` go to the candidate list as (rank | count << 16); everything
+// read is cleared.  A thread's eight vectors are read back to back into registers (one LDS round trip,
+// not eight) and cleared; its hits are counted (one SWAR test per word), ONE atomic reserves their
+// places in the list, and a pass over the registers writes them -- instead of one returning atomic per
+// hit, which the scan would wait on hit after hit.
+template <bool WIDE>
+__device__ __forceinline__ void ws_scan_fast(uint4* cnt128, uint32_t* cand, uint32_t* n_cand, uint32_t* cand_ov,
+                                             uint32_t need, uint32_t h, uint32_t wlen) {
+  const WsLayout<WIDE> Y(need, h, wlen);
+  const uint32_t tid = threadIdx.x;
+  constexpr uint32_t kRound = 4;                           // vectors of a thread in flight together
+#pragma unroll 1
+  for (uint32_t k0 = 0; k0 < kWsCntWords / 4 / kWsNT; k0 += kRound) {
+    uint4 v[kRound];
+#pragma unroll
+    for (uint32_t k = 0; k < kRound; ++k) {
+      const uint32_t i = tid + (k0 + k) * kWsNT;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (i < Y.nv) v[k] = cnt128[i];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kRound; ++k) {
+      const uint32_t i = tid + (k0 + k) * kWsNT;
+      uint32_t z = 0;
+      asm volatile("" : "+v"(z));
+      if (i < Y.nv) cnt128[i] = make_uint4(z, z, z, z);
+    }
+    v[kRound - 1] = Y.mask_pad(v[kRound - 1], tid + (k0 + kRound - 1) * kWsNT);
+    // most counters are zero and nearly all are below `need`: one AND per word tells whether any counter
+    // of the round can reach it at all, before the exact SWAR test
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kRound; ++k) any |= (v[k].x | v[k].y | v[k].z | v[k].w) & Y.pre;
+    if (any == 0) continue;
+    uint32_t n_hit = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kRound; ++k)
+      n_hit += __popc(Y.hits(v[k].x)) + __popc(Y.hits(v[k].y)) + __popc(Y.hits(v[k].z)) + __popc(Y.hits(v[k].w));
+    if (n_hit == 0) continue;
+    uint32_t at = atomicAdd(n_cand, n_hit);
+    if (at + n_hit > kWsCand) { *cand_ov = 1; continue; }  // the window is swept again, the robust way
+#pragma unroll
+    for (uint32_t k = 0; k < kRound; ++k) {
+      const uint32_t d[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      if ((d[0] | d[1] | d[2] | d[3]) == 0) continue;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        uint32_t m = Y.hits(d[j]);
+        while (m) {
+          const uint32_t bit = __ffs(m) - 1;
+          m &= m - 1;
+          cand[at++] = Y.rank16(tid + (k0 + k) * kWsNT, j, bit) | (Y.count(d[j], bit) << 16);
+        }
+      }
+    }
+  }
+}
+
+// Robust scan (no threshold yet, or a candidate list that overflowed): nothing is left out of the count,
+// so a counter IS the match count and a hit goes straight to the pool if its key beats the threshold --
+// only such hits take room, so a flood of ties behind the threshold's rank cannot fill anything.
+template <bool WIDE>
+__device__ __forceinline__ void ws_scan_robust(const FindArgs& A, uint4* cnt128, Control* ctl, unsigned long long* pool,
+                                               unsigned long long thr, uint32_t T, uint32_t wbase, uint32_t need,
+                                               uint32_t h, uint32_t wlen) {
+  const WsLayout<WIDE> Y(need, h, wlen);
+#pragma unroll 1
+  for (uint32_t i = threadIdx.x; i < Y.nv; i += kWsNT) {
+    const uint4 v = Y.mask_pad(cnt128[i], i);
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    cnt128[i] = make_uint4(z, z, z, z);
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4; ++j) {
+      uint32_t m = Y.hits(d[j]);
+      while (m) {
+        const uint32_t bit = __ffs(m) - 1;
+        m &= m - 1;
+        ws_admit(A, ctl, pool, thr, T, wbase, Y.rank16(i, j, bit), Y.count(d[j], bit));
+      }
+    }
+  }
+}
+
+// phase clocks of wave 0 (stats mode only): FindArgs::stats[kStatWsClocks + phase]
+#define WS_CLOCK(i) do { if (A.stats && wid == 0) { const unsigned long long t_ = clock64(); ws_clk[i] += t_ - ws_last; ws_last = t_; } } while (0)
+
+__global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, const uint32_t w, const uint32_t n,
+                                                          const uint32_t chunk_len) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];       // + dump word
+  __shared__ uint32_t s_cand[kWsCand];
+  __shared__ unsigned long long s_pool[kWsPool];
+  __shared__ uint32_t s_task_q[kWsNT], s_task_meta[kWsNT], s_task_code[kWsNT];
+  __shared__ WsControl s_ctl;
+  uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
+  Control* ctl = &s_ctl.c;
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t wbase = w * kWindowRanks;
+  const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+  const uint32_t wmt = A.win_max_tri[w];
+  const uint32_t keep = A.keep;
+  const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
+  const uint32_t* bmid = A.bm_id + size_t(w) * kNumCodes;
+
+  for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
+  // request counters (FindArgs::stats), per wave
+  uint32_t st_ent = 0, st_probe = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0;
+  unsigned long long ws_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_last = clock64();
+
+  for (;;) {
+    if (tid == 0) { s_ctl.chunk = atomicAdd(A.queue, 1u); s_ctl.n_tasks = 0; }
+    ws_barrier();
+    const uint32_t base = s_ctl.chunk * chunk_len;           // chunk_len <= kWsNT needles per queue pop
+    if (base >= n) break;
+    // ---- which of these needles have anything to gain from this window? ----------------------
+    {
+      const uint32_t q = base + tid;
+      bool live = q < n && tid < chunk_len;
+      uint32_t T = 0, cnt = 0, need = 0;
+      if (live) { T = A.q_ntri[q]; live = T <= 64 && A.q_nb[q] != 0; }
+      if (live) { const uint32_t own0 = A.q_start[q] & ~1u; live = !(w >= own0 && w < own0 + 2); }   // phase 1 did those
+      if (live) {
+        cnt = A.counts[q];
+        const unsigned long long thr = cnt >= keep ? ws_load_key(A, q, keep - 1) : kKeyInf;
+        need = matches_needed(thr, T, wbase);
+        live = min(T, wmt) >= need;
+      }
+      if (live) {
+        const uint32_t at = atomicAdd(&s_ctl.n_tasks, 1u);
+        s_task_q[at] = q;
+        s_task_meta[at] = T | (cnt << 8);
+        s_task_code[at] = uint32_t(A.offsets[q]) + q;        // the needle's codes in qcodes (the host checked 32 bits)
+      }
+    }
+    ws_barrier();
+    const uint32_t n_tasks = s_ctl.n_tasks;
+    WS_CLOCK(0);
+
+    // the slice table of the next task travels while the current one is counted: codes first, then
+    // (start, end, bitmap) of the needle's slices in this window, one per lane, a copy in every wave
+    uint32_t nx_code = 0, nx_ta = 0, nx_tb = 0, nx_bm = kNoBitmap;
+#define WS_FETCH_CODES(ti_)                                                               \
+  do {                                                                                    \
+    nx_code = 0;                                                                          \
+    if ((ti_) < n_tasks && lane < (s_task_meta[ti_] & 0xFFu)) nx_code = A.qcodes[s_task_code[ti_] + lane]; \
+  } while (0)
+#define WS_FETCH_TABLE(ti_)                                                               \
+  do {                                                                                    \
+    nx_ta = nx_tb = 0; nx_bm = kNoBitmap;                                                 \
+    if ((ti_) < n_tasks && lane < (s_task_meta[ti_] & 0xFFu)) {                           \
+      nx_ta = soff[nx_code]; nx_tb = soff[nx_code + 1]; nx_bm = bmid[nx_code];            \
+    }                                                                                     \
+  } while (0)
+    WS_FETCH_CODES(0u);
+    WS_FETCH_TABLE(0u);
+    WS_FETCH_CODES(1u);
+
+    for (uint32_t ti = 0; ti < n_tasks; ++ti) {
+      const uint32_t q = s_task_q[ti];
+      const uint32_t meta = s_task_meta[ti];
+      const uint32_t T = meta & 0xFFu, cnt0 = meta >> 8;
+      // ---- the needle's state: its best keys so far (needed when a candidate is admitted) ------
+      unsigned long long my_key = kKeyInf;
+      if (tid < cnt0) my_key = ws_load_key(A, q, tid);
+      const bool own = lane < T;
+      const uint32_t ta = nx_ta, tb0 = nx_tb, bm = nx_bm;     // (waits for the prefetched table)
+      WS_FETCH_TABLE(ti + 1);                                 // the next task's codes arrived a task ago
+      if (A.stats) { st_tab += 3 * T; ++st_tasks; }
+      if (tid < cnt0) s_pool[tid] = my_key;
+      if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
+      if (tid == keep - 1 || (tid == 0 && cnt0 < keep)) ctl->thr = cnt0 >= keep ? my_key : kKeyInf;
+      ws_barrier();
+      WS_FETCH_CODES(ti + 2);
+      bool changed = false;
+      bool robust = cnt0 < keep;                             // no threshold yet: nothing can be left out
+      WS_CLOCK(1);
+
+      for (;;) {                                           // again after an overflow (rare)
+        const unsigned long long thr = ctl->thr;
+        const uint32_t pool_at_start = ctl->pool_n;
+        const uint32_t need = matches_needed(thr, T, wbase);
+        if (min(T, wmt) < need) break;                     // (the threshold tightened in an earlier pass)
+        // ---- which dense slices are left out: the L largest, L <= need - cmin ------------------
+        const uint32_t l_max = (!robust && need > A.cmin) ? need - A.cmin : 0u;
+        const uint32_t size = tb0 - ta;
+        const bool dense = own && bm != kNoBitmap && size > 0;
+        uint32_t bigger = 0;
+        if (l_max)
+          for (unsigned long long m = __ballot(dense); m; m &= m - 1) {
+            const uint32_t u = __builtin_ctzll(m);
+            const uint32_t su = __builtin_amdgcn_readlane(size, u);
+            bigger += (su > size || (su == size && u < lane)) ? 1u : 0u;
+          }
+        const bool skip = dense && bigger < l_max;
+        const unsigned long long skipmask = __ballot(skip);
+        const uint32_t L = __popcll(skipmask);
+        const uint32_t need_eff = need - L;                // >= cmin >= 1 when L > 0
+        const uint32_t tb = skip ? ta : tb0;
+        if (__ballot(tb > ta) == 0) break;                 // nothing to count: nothing can reach need_eff >= 1
+        const bool wide = min(T - L, wmt) > 15;            // a cold count could overflow four bits
+        ++st_steps;
+        WS_CLOCK(6);                                       // the left-out set chosen
+
+        for (uint32_t h = 0; h < (wide ? 2u : 1u); ++h) {
+          // ---- count: this wave's units of the slices that are not left out.  The wave first lists its
+          // units -- lane k keeps unit k's (first entry, slice end) -- then streams them four at a time:
+          // four loads travel together, one memory round trip per four units, not one per unit. ----------
+          {
+            uint32_t my_c = 0, my_e = 0, nu = 0;
+            auto flush = [&]() {
+              for (uint32_t g = 0; g < nu; g += 4) {
+                uint4 u[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                  const uint32_t c = __builtin_amdgcn_readlane(my_c, (g + j) & 63u);
+                  const uint32_t e = (g + j) < nu ? __builtin_amdgcn_readlane(my_e, (g + j) & 63u) : 0u;
+                  u[j] = load_group(A.ent, c + lane * 8, e);
+                  if (A.stats && (g + j) < nu) st_ent += min(512u, e - c);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                  if (wide) ws_bump8<true>(s_cnt, u[j], h); else ws_bump8<false>(s_cnt, u[j], 0u);
+                }
+              }
+              nu = 0;
+            };
+            unsigned long long mask = __ballot(((wid - lane) & (kWsNW - 1)) < slice_units(ta, tb));
+            while (mask) {
+              const uint32_t t = __builtin_ctzll(mask);
+              mask &= mask - 1;
+              const uint32_t sa = __builtin_amdgcn_readlane(ta, t), sb = __builtin_amdgcn_readlane(tb, t);
+              const uint32_t su = slice_units(sa, sb);
+              for (uint32_t j = (wid - t) & (kWsNW - 1); j < su; j += kWsNW) {
+                if (lane == nu) { my_c = sa + j * 512; my_e = sb; }
+                if (++nu == 64) flush();
+              }
+            }
+            flush();
+          }
+          WS_CLOCK(7);                                     // units listed, loaded, counted
+          ws_barrier();
+          WS_CLOCK(2);                                     // barrier after the count
+          // ---- scan: counters that reach need_eff become candidates; everything is cleared -------
+          if (!robust) {
+            if (wide) ws_scan_fast<true>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, h, wlen);
+            else      ws_scan_fast<false>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, 0u, wlen);
+          } else {
+            uint32_t floor_need = need_eff;                // (== need: nothing is left out)
+            if (!wide && thr == kKeyInf && T > 1 && !A.tomb) {
+              // no threshold at all: admit only counters that can be among the best `keep` of this window
+              // alone (cold_start_need's argument), found by bisection over the counter value
+              uint32_t lo = 1, hi = min(T, 15u);
+              const uint32_t nv = (wlen + 31) / 32;
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (tid == 0) ctl->tally = 0;
+                ws_barrier();
+                const WsLayout<false> Y(mid, 0u, wlen);
+                uint32_t mine = 0;
+                for (uint32_t i = tid; i < nv; i += kWsNT) {
+                  const uint4 v = Y.mask_pad(cnt128[i], i);
+                  mine += __popc(Y.hits(v.x)) + __popc(Y.hits(v.y)) + __popc(Y.hits(v.z)) + __popc(Y.hits(v.w));
+                }
+#pragma unroll
+                for (uint32_t dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, int(dd));
+                if (lane == 0 && mine) atomicAdd(&ctl->tally, mine);
+                ws_barrier();
+                if (ctl->tally >= keep) lo = mid; else hi = mid - 1;
+                ws_barrier();
+              }
+              floor_need = max(floor_need, lo);
+            }
+            if (wide) ws_scan_robust<true>(A, cnt128, ctl, s_pool, thr, T, wbase, floor_need, h, wlen);
+            else      ws_scan_robust<false>(A, cnt128, ctl, s_pool, thr, T, wbase, min(floor_need, 16u), 0u, wlen);
+          }
+          // what no vector reached: the padding slot (short window), the dump word of the byte halves
+          if (tid == 0) {
+            const uint32_t nv_here = wide ? WsLayout<true>(1u, h, wlen).nv : WsLayout<false>(1u, 0u, wlen).nv;
+            if (nv_here < kWsCntWords / 4) s_cnt[kWsCntWords - 1] = 0;
+            if (wide) s_cnt[kWsCntWords] = 0;
+          }
+          ws_barrier();
+          WS_CLOCK(3);
+        }
+        // ---- probe: the left-out slices' bitmaps give every candidate its exact match count.  A
+        // thread owns candidates tid and tid + 256; four slices' words travel together. ----------------
+        if (!robust && !s_ctl.cand_ov) {                    // (an overflowed list is abandoned: the robust pass redoes it all)
+          const uint32_t n_cand = s_ctl.n_cand;
+          if (A.stats && wid == 0) st_probe += n_cand * L;
+          const bool has0 = tid < n_cand, has1 = tid + kWsNT < n_cand;
+          const uint32_t c0 = has0 ? s_cand[tid] : 0u, c1 = has1 ? s_cand[tid + kWsNT] : 0u;
+          const uint32_t r0 = c0 & 0xFFFFu, r1 = c1 & 0xFFFFu;
+          uint32_t t0 = c0 >> 16, t1 = c1 >> 16;
+          if (__ballot(has0)) {
+            unsigned long long m = skipmask;
+            while (m) {
+              uint32_t id[4], x0[4], x1[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                id[j] = kNoBitmap;
+                if (m) { id[j] = __builtin_amdgcn_readlane(bm, __builtin_ctzll(m)); m &= m - 1; }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                x0[j] = x1[j] = 0;
+                if (id[j] != kNoBitmap) {                                  // (uniform)
+                  const uint32_t* bmw = A.bitmaps + size_t(id[j]) * kBitmapWords;
+                  if (has0) x0[j] = bmw[r0 >> 5];
+                  if (has1) x1[j] = bmw[r1 >> 5];
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { t0 += (x0[j] >> (r0 & 31)) & 1u; t1 += (x1[j] >> (r1 & 31)) & 1u; }
+            }
+            if (has0) ws_admit(A, ctl, s_pool, thr, T, wbase, r0, t0);
+            if (has1) ws_admit(A, ctl, s_pool, thr, T, wbase, r1, t1);
+          }
+          ws_barrier();
+        }
+        WS_CLOCK(4);
+        // ---- select ---------------------------------------------------------------------------
+        const uint32_t cov = s_ctl.cand_ov;
+        const uint32_t ov = ctl->overflow | cov, pn = ctl->pool_n;
+        if (!ov && pn == pool_at_start) break;                           // nothing was admitted
+        ws_barrier();
+        if (tid == 0) { s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
+        ++st_compact;
+        ws_compact_pool(s_pool, ctl, keep, pool_at_start);
+        changed = true;
+        if (!ov) break;
+        // An overflow: candidates of this window were lost.  Keep the tightened threshold, forget this
+        // window's survivors and sweep it again (every pass shrinks the admitted set) -- the robust way
+        // if it was the candidate list that overflowed.
+        ++st_redo;
+        if (cov) robust = true;
+        if (tid == 0) {
+          uint32_t j = 0;
+          const uint32_t np = ctl->pool_n;
+          for (uint32_t i = 0; i < np; ++i)
+            if (uint32_t(s_pool[i]) - wbase >= wlen) s_pool[j++] = s_pool[i];
+          ctl->pool_n = j;
+        }
+        ws_barrier();
+      }
+      // ---- write the state back if it changed --------------------------------------------------
+      ws_barrier();
+      if (changed) {
+        const uint32_t pn = ctl->pool_n;                                  // sorted, <= keep
+        uint32_t* st = reinterpret_cast<uint32_t*>(A.results + size_t(q) * A.limit);
+        if (tid < pn) {
+          const unsigned long long key = s_pool[tid];
+          st[2 * tid] = uint32_t(key); st[2 * tid + 1] = uint32_t(key >> 32);
+        }
+        if (tid == 0) A.counts[q] = pn;
+      }
+      ws_barrier();                                     // pool and control quiet before the next task
+      WS_CLOCK(5);
+    }
+#undef WS_FETCH_TABLE
+#undef WS_FETCH_CODES
+  }
+  if (A.stats && lane == 0) {
+    atomicAdd(&A.stats[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    if (wid == 0) {
+      atomicAdd(&A.stats[kStatProbes], static_cast<unsigned long long>(st_probe));
+      atomicAdd(&A.stats[kStatTableWords], static_cast<unsigned long long>(st_tab) * kWsNW);
+      atomicAdd(&A.stats[kStatSteps], static_cast<unsigned long long>(st_steps));
+      atomicAdd(&A.stats[kStatResweeps], static_cast<unsigned long long>(st_redo));
+      atomicAdd(&A.stats[kStatTasks], static_cast<unsigned long long>(st_tasks));
+      atomicAdd(&A.stats[kStatCompactions], static_cast<unsigned long long>(st_compact));
+      for (int i = 0; i < 8; ++i) atomicAdd(&A.stats[kStatWsClocks + i], ws_clk[i]);
+    }
+  }
+}
+#undef WS_CLOCK
+
+// keys -> rows, in place: a needle's keys occupy the first 8 bytes of every 12-byte row slot's
+// worth of its result area (2 words per key, packed), so rows are written from the last to the
+// first -- row i lands on keys >= i only.  One lane per needle.
+__global__ void finalize_rows_kernel(const FindArgs A, const uint32_t n) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const uint32_t T = A.q_ntri[q];
+  if (T > 64 || A.q_nb[q] == 0) return;                    // not a needle of the window-major sweep
+  const uint32_t cnt = A.counts[q];
+  uint32_t* st = reinterpret_cast<uint32_t*>(A.results + size_t(q) * A.limit);
+  for (uint32_t i = cnt; i-- > 0;) {
+    const uint32_t rank = st[2 * i], miss = st[2 * i + 1];
+    const uint32_t ref = A.ref_of_rank[rank], weight = A.weight_of_rank[rank];
+    st[3 * i] = ref; st[3 * i + 1] = T - miss; st[3 * i + 2] = weight;
+  }
+}
+
 // dynamic LDS of find_kernel (the counters are static)
 size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
   static_assert(sizeof(Control) <= 64, "the unit ring sits 64 bytes behind the control block");
@@ -1482,6 +2054,26 @@ int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) 
     BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_parts_kernel<NT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((merge_parts_kernel<NT>), dim3(n_items), dim3(NT), lds, stream, a);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hipStream_t stream) {
+  if (n == 0) return 0;
+  // needles per queue pop: whole 256-thread filters for big batches, smaller chunks when there are too
+  // few needles to give every resident workgroup (four per CU) several chunks
+  uint32_t chunk_len = kWsNT;
+  while (chunk_len > 16 && (n + chunk_len - 1) / chunk_len < n_cus * 4u * 4u) chunk_len >>= 1;
+  const uint32_t chunks = (n + chunk_len - 1) / chunk_len;
+  const uint32_t grid = std::min(chunks, n_cus * 4u);
+  hipLaunchKernelGGL(wsweep_kernel, dim3(grid), dim3(kWsNT), 0, stream, a, w, n, chunk_len);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, n);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,150 @@
+"""GPU parity of the window-major sweep (find_kernels.hip: wsweep_kernel -- hot slices left out of the
+count and consulted through bitmaps, one launch per window, needle states in global memory) against
+the oracle, bit-exact, and against the needle-major sweep it replaces for large batches.
+
+The path is taken for batches of >= 16 384 needles (BLURRILY_WS_MIN_NEEDLES) over >= 8 windows
+(BLURRILY_WS_MIN_WINDOWS) with limit <= 128 whose slices are big (BLURRILY_WS_MIN_SLICE: the path
+pays a fixed price per (needle, window)); the tests lower those bounds through the environment
+(read at every find call) to reach it with haystacks the oracle checks in seconds."""
+import os
+
+import numpy as np
+import pytest
+
+import workloads as W
+from blurrily_amd import RawMap
+from blurrily_amd.map import _pack
+from helpers import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def ws_env():
+    keys = ("BLURRILY_WSWEEP", "BLURRILY_WS_CMIN", "BLURRILY_WS_MIN_WINDOWS", "BLURRILY_WS_MIN_NEEDLES",
+            "BLURRILY_WS_MIN_SLICE")
+    saved = {k: os.environ.get(k) for k in keys}
+
+    def set_(**kw):
+        kw.setdefault("WS_MIN_SLICE", 0)                       # whatever the haystack's slice sizes
+        for k, v in kw.items():
+            os.environ["BLURRILY_" + k] = str(v)
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _pair(hay, off):
+    n = len(off) - 1
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    o.put_many(hay, off)
+    return m, o
+
+
+def _check_all(m, o, packed, off, limit, took_ws=True):
+    m.set_stats(True)
+    rows, counts = m.find_batch_packed(packed, off, limit)
+    st = m.find_stats()
+    m.set_stats(False)
+    assert (st["probes"] > 0) == took_ws, st                   # the window-major path really ran (or did not)
+    want = o.batch(packed, off, limit=limit)
+    assert np.array_equal(counts, want["counts"])
+    live = np.arange(limit)[None, :] < counts[:, None].astype(np.int64)
+    bad = np.nonzero((np.where(live[:, :, None], rows, 0) != np.where(live[:, :, None], want["rows"], 0)).any(axis=(1, 2)))[0]
+    if len(bad):
+        q = int(bad[0])
+        nd = bytes(packed[int(off[q]):int(off[q + 1])])
+        raise AssertionError((len(bad), q, nd, rows[q, :counts[q]].tolist(), want["rows"][q, :counts[q]].tolist()))
+    return rows, counts
+
+
+def _mixed_needles(hay, off, n_q, seed):
+    """Edited haystack strings plus the awkward ones: whole long strings (many trigrams: byte counters
+    over window halves), gibberish (no threshold for a long time), empty, one letter, > 64 trigrams."""
+    q, qo = W.queries(hay, off, n_q, seed)
+    needles = W.unpack(q, qo)
+    rng = np.random.default_rng(seed)
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    longest = np.argsort(lens)[-400:]
+    for i in longest:
+        needles.append(bytes(hay[int(off[i]):int(off[i + 1])]))
+    for _ in range(300):
+        needles.append(bytes(rng.choice(list(b"qxzjkvw"), size=int(rng.integers(1, 9))).tolist()))
+    needles += [b"", b"a", b" ", b"zzzzzzzz", b"e", b"the", b"abcdefghij klmnopqrst uvwxyz abcdefgh ijklmnopqr stuvwxyz zyxwvutsrq ponmlkji"]
+    order = rng.permutation(len(needles))
+    return _pack([needles[i] for i in order])
+
+
+@pytest.mark.parametrize("limit,cmin", [(10, 2), (10, 1), (10, 3), (100, 2), (128, 2), (1, 2), (3, 2)])
+def test_geonames_medium_all_rows_vs_oracle(ws_env, limit, cmin):
+    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000, WS_CMIN=cmin)
+    hay, off = W.geonames(600000, 80000, 41)                   # 10 windows
+    m, o = _pair(hay, off)
+    packed, offs = _mixed_needles(hay, off, 6000, 42)
+    _check_all(m, o, packed, offs, limit)
+
+
+def test_window_major_equals_needle_major(ws_env):
+    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+    hay, off = W.geonames(900000, 120000, 43)
+    m, _ = _pair(hay, off)
+    packed, offs = _mixed_needles(hay, off, 30000, 44)
+    a_rows, a_counts = m.find_batch_packed(packed, offs, 10)
+    ws_env(WSWEEP=0)
+    b_rows, b_counts = m.find_batch_packed(packed, offs, 10)
+    assert np.array_equal(a_counts, b_counts)
+    live = np.arange(10)[None, :] < a_counts[:, None].astype(np.int64)
+    assert np.array_equal(np.where(live[:, :, None], a_rows, 0), np.where(live[:, :, None], b_rows, 0))
+
+
+def test_skewed_ties_and_limit_100(ws_env):
+    """Massive (matches, weight) ties: floods of equally good candidates, pool overflows, re-sweeps."""
+    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+    hay, off = W.skewed(600000, 45)
+    m, o = _pair(hay, off)
+    q, qo = W.queries(hay, off, 2500, 46)
+    _check_all(m, o, q, qo, 100)
+    _check_all(m, o, q, qo, 10)
+
+
+def test_words_many_windows(ws_env):
+    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+    hay, off = W.words(400000, 47)                             # 7 windows of single words
+    m, o = _pair(hay, off)
+    q, qo = W.queries(hay, off, 8000, 48)
+    _check_all(m, o, q, qo, 10)
+
+
+def test_tombstones_and_pending_puts_under_the_window_major_sweep(ws_env):
+    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+    hay, off = W.geonames(500000, 60000, 49)
+    m, o = _pair(hay, off)
+    q, qo = W.queries(hay, off, 4000, 50)
+    _check_all(m, o, q, qo, 10)                                # builds the base image
+    needles = W.unpack(q, qo)
+    rng = np.random.default_rng(51)
+    # delete the best match of many needles (tombstones on the base image), add new strings (delta image)
+    rows, counts = m.find_batch_packed(q, qo, 10)
+    victims = sorted({int(rows[i, 0, 0]) for i in rng.choice(len(needles), size=1500, replace=False) if counts[i]})
+    for ref in victims:
+        assert m.delete(ref) == o.delete(ref)
+    n = len(off) - 1
+    for j, i in enumerate(rng.choice(len(needles), size=300, replace=False)):
+        ref = n + 1 + j
+        assert m.put(needles[i], ref, 0) == o.put(needles[i], ref, 0)
+    info = m.device_info()
+    _check_all(m, o, q, qo, 10)
+    info = m.device_info()
+    assert info["base_builds"] == 1 and info["n_tombstones"] == len(victims) and info["n_pending"] == 300
+
+
+def test_small_batches_and_small_haystacks_keep_the_needle_major_path(ws_env):
+    ws_env()
+    hay, off = W.geonames(600000, 80000, 41)
+    m, o = _pair(hay, off)
+    q, qo = W.queries(hay, off, 500, 52)                       # default bounds: 500 needles is a small batch
+    _check_all(m, o, q, qo, 10, took_ws=False)
