@@ -250,10 +250,22 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     stats_rows_equal = bool(np.array_equal(gpu_counts, block.counts.cpu().numpy().view(np.uint32)))
     out_bytes = 12 * sum_rows + 4 * n_q + 4 * n_q                              # rows + counts + nb_entries
     needle_bytes = int(qo[-1]) + 8 * (n_q + 1) + 2 * (int(qo[-1]) + n_q)       # needles, offsets, code scratch (w+r)
-    phys_bytes = (2 * st["posting_entries"] + 4 * st["table_words"] + 4 * st["bitmap_words"] +
-                  4 * st["probes"] + out_bytes + 2 * needle_bytes)
-    phys_gbs = phys_bytes / (k_ms * 1e-3) / 1e9
+    req_bytes = (2 * st["posting_entries"] + 4 * st["table_words"] + 4 * st["probes"] + out_bytes + 2 * needle_bytes)
+    req_gbs = req_bytes / (k_ms * 1e-3) / 1e9
     lds_lanes = st["posting_entries"] / (k_ms * 1e-3)
+    # memory-side bytes per step from the rocprofv3 --pmc passes of this workload (a separate run of this
+    # command under the profiler, profiles/): the L2's fabric-side counters, i.e. HBM + Infinity Cache
+    pmc_bytes, pmc_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath) and args.scale == 1.0:
+        try:
+            pmc_bytes = json.load(open(tpath)).get(name)
+            pmc_src = ("profiles/traffic_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KiB of this workload's find kernels, "
+                       "rocprofv3 --pmc, separate run (tools/collect_profiles.sh); includes Infinity-Cache hits")
+        except Exception:
+            pmc_bytes = None
+    phys_bytes = pmc_bytes if pmc_bytes else req_bytes
+    phys_gbs = phys_bytes / (k_ms * 1e-3) / 1e9
 
     totals = torch.tensor([float(sum_nb), k_ms, float(np.mean(gather_ms)) if gather_ms else 0.0],
                           dtype=torch.float64, device=dev)
@@ -306,10 +318,13 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "bound": "hbm", "achieved": phys_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": phys_gbs / HBM_PEAK_GBS,
                 "traffic": phys_bytes,
-                "traffic_source": "bytes requested by the kernels in one launch of this batch, counted in-kernel "
-                                  "(blurrily_storage_set_stats) in an extra untimed launch of this run; the "
-                                  "rocprofv3 --pmc cross-check is under profiles/",
-                "kernel": "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024"),
+                "traffic_source": pmc_src or "no PMC file for this workload: the bytes the kernels REQUESTED (below), an "
+                                             "upper bound on memory-side bytes only when nothing is re-used from cache",
+                # what the kernels asked of the memory system in one launch sequence of this batch, counted exactly
+                # in-kernel (blurrily_storage_set_stats) in an extra untimed launch of THIS run; L2 hits included
+                "requested_bytes": req_bytes, "requested_gbs": req_gbs,
+                "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if st["probes"] else
+                           "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024")),
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_gbs": algo_bytes / (k_ms * 1e-3) / 1e9,

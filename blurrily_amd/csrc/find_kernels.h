@@ -81,7 +81,7 @@ enum : uint32_t {
   kStatTasks          = 3,   // needles (or needle ranges) swept
   kStatCompactions    = 4,   // candidate-pool compactions
   kStatResweeps       = 5,   // windows swept again after a pool overflow
-  kStatBitmapWords    = 6,   // (reserved)
+  kStatUnits          = 6,   // wave-loads of postings (up to 512 each) issued by the window-major sweep
   kStatProbes         = 7,   // bitmap words read for candidates of the window-major sweep (x4 = bytes)
   kStatSlots          = 8,   // what blurrily_storage_find_stats reports
   kStatWsClocks       = 8,   // + 0..5: shader clocks of wave 0 per phase of wsweep_kernel, summed over workgroups

@@ -1433,6 +1433,7 @@ struct WsControl {
   uint32_t cand_ov;           // the candidate list overflowed in this pass
   uint32_t n_tasks;
   uint32_t chunk;
+  uint32_t pub_units, pub_L, pub_wide;   // published by the task's owner wave with s_units / s_hot
 };
 
 __device__ __forceinline__ unsigned long long ws_load_key(const FindArgs& A, uint32_t q, uint32_t i) {
@@ -1440,9 +1441,16 @@ __device__ __forceinline__ unsigned long long ws_load_key(const FindArgs& A, uin
   return (static_cast<unsigned long long>(st[2 * i + 1]) << 32) | st[2 * i];
 }
 
-// one posting into the single-window 4-bit layout: rank r -> word r >> 3, nibble r & 7
+// One posting into the single-window 4-bit layout.  The index deals the postings of a unit so that one
+// LDS instruction sees each BYTE-counter bank once (bank = (r >> 2) & 31, device_index.hip); the 4-bit
+// layout keeps that bank: rank r -> word (r >> 2) & 0x1FFF, i.e. byte address r & 0x7FFC, and nibble
+// (r & 3) | (r >> 15) << 2 -- a word holds ranks 4w..4w+3 of the window's lower half in its low nibbles
+// and ranks 32768 + 4w.. of the upper half in its high ones.  (With word = r >> 3, 61 % of the LDS-active
+// cycles were bank conflicts, profiles/r02_ws_pmc.txt.)
 __device__ __forceinline__ void ws_bump_nib(uint32_t* cnt32, uint32_t r) {
-  __hip_atomic_fetch_add(&cnt32[r >> 3], 1u << ((r << 2) & 28u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t sh = ((r & 3u) << 2) | ((r >> 11) & 16u);
+  __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cnt32) + (r & 0x7FFCu)), 1u << sh,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // one posting into the half-window byte layout: rank r of half `h` -> byte r & 0x7FFF; a posting of the
 // other half goes to a dump word behind the counters
@@ -1503,7 +1511,8 @@ __device__ __forceinline__ void ws_compact_pool(unsigned long long* pool, Contro
 }
 
 // What the scans need to know about the two counter layouts of wsweep_kernel.
-//   WIDE = false: 4-bit counters, the whole window: vector i holds in-window ranks [32 i, 32 i + 32)
+//   WIDE = false: 4-bit counters, the whole window: word w holds ranks 4w..4w+3 (nibbles 0..3) and
+//                 32768 + 4w.. (nibbles 4..7), see ws_bump_nib; vector i = words 4i..4i+3
 //   WIDE = true : byte counters of half h of the window: vector i holds ranks [32768 h + 16 i, ... + 16)
 template <bool WIDE> struct WsLayout {
   static constexpr uint32_t kRanksPerVec = WIDE ? 16 : 32, kBits = WIDE ? 8 : 4, kPerWord = WIDE ? 4 : 8;
@@ -1522,7 +1531,7 @@ template <bool WIDE> struct WsLayout {
     } else {
       low = need <= 8;                                     // counter >= need, c = counter, lo = c & 7:
       bias = (low ? 8 - need : 16 - need) * 0x11111111u;   //   need <= 8: c >= 8 or lo + (8 - need) >= 8
-      lo_r = 0; nv = (wlen + 31) / 32; pad_here = true;    //   need >  8: c >= 8 and lo + (16 - need) >= 8
+      lo_r = 0; nv = (min(wlen, 32768u) + 15) / 16; pad_here = true;   // need > 8: c >= 8 and lo + (16 - need) >= 8
     }
   }
   // one bit per counter that reached `need`, at the top bit of its field
@@ -1536,7 +1545,9 @@ template <bool WIDE> struct WsLayout {
     return v;
   }
   __device__ __forceinline__ uint32_t rank16(uint32_t i, uint32_t j, uint32_t bit) const {
-    return lo_r + i * kRanksPerVec + j * kPerWord + bit / kBits;
+    if (WIDE) return lo_r + i * 16 + j * 4 + bit / 8;
+    const uint32_t nib = bit / 4;                          // nibbles 0..3: lower half of the window, 4..7: upper half
+    return (i * 4 + j) * 4 + (nib & 3u) + (nib >> 2) * 32768u;
   }
   __device__ __forceinline__ uint32_t count(uint32_t d, uint32_t bit) const {
     return (d >> (bit / kBits * kBits)) & ((1u << kBits) - 1u);
@@ -1650,6 +1661,8 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
   __shared__ uint32_t s_cand[kWsCand];
   __shared__ unsigned long long s_pool[kWsPool];
   __shared__ uint32_t s_task_q[kWsNT], s_task_meta[kWsNT], s_task_code[kWsNT];
+  __shared__ uint2 s_units[64];                 // what the owner wave publishes: the units to count (first entry, slice end)
+  __shared__ uint32_t s_hot[64];                //   ... and the bitmaps of the slices it left out
   __shared__ WsControl s_ctl;
   uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
   Control* ctl = &s_ctl.c;
@@ -1664,7 +1677,7 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
 
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   // request counters (FindArgs::stats), per wave
-  uint32_t st_ent = 0, st_probe = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0;
+  uint32_t st_ent = 0, st_probe = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0, st_units = 0;
   unsigned long long ws_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_last = clock64();
 
   for (;;) {
@@ -1696,8 +1709,11 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
     const uint32_t n_tasks = s_ctl.n_tasks;
     WS_CLOCK(0);
 
-    // the slice table of the next task travels while the current one is counted: codes first, then
-    // (start, end, bitmap) of the needle's slices in this window, one per lane, a copy in every wave
+    // Tasks go in groups of four.  Wave j OWNS task g + j of the group: it alone holds the needle's slice
+    // table for this window (start, end, bitmap of every trigram's slice, one per lane), chooses the slices
+    // to leave out and lists the units to count; the other waves only ever see what it publishes through
+    // LDS.  The four tables of a group are fetched by the four waves side by side, those of the next group
+    // while this one is being worked on.
     uint32_t nx_code = 0, nx_ta = 0, nx_tb = 0, nx_bm = kNoBitmap;
 #define WS_FETCH_CODES(ti_)                                                               \
   do {                                                                                    \
@@ -1711,222 +1727,248 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
       nx_ta = soff[nx_code]; nx_tb = soff[nx_code + 1]; nx_bm = bmid[nx_code];            \
     }                                                                                     \
   } while (0)
-    WS_FETCH_CODES(0u);
-    WS_FETCH_TABLE(0u);
-    WS_FETCH_CODES(1u);
+    WS_FETCH_CODES(wid);
+    WS_FETCH_TABLE(wid);
+    WS_FETCH_CODES(kWsNW + wid);
 
-    for (uint32_t ti = 0; ti < n_tasks; ++ti) {
-      const uint32_t q = s_task_q[ti];
-      const uint32_t meta = s_task_meta[ti];
-      const uint32_t T = meta & 0xFFu, cnt0 = meta >> 8;
-      // ---- the needle's state: its best keys so far (needed when a candidate is admitted) ------
-      unsigned long long my_key = kKeyInf;
-      if (tid < cnt0) my_key = ws_load_key(A, q, tid);
-      const bool own = lane < T;
+    for (uint32_t g = 0; g < n_tasks; g += kWsNW) {
+      // this wave's own task of the group
+      const uint32_t my_ti = g + wid;
+      const uint32_t my_T = my_ti < n_tasks ? (s_task_meta[my_ti] & 0xFFu) : 0u;
+      const bool own = lane < my_T;
       const uint32_t ta = nx_ta, tb0 = nx_tb, bm = nx_bm;     // (waits for the prefetched table)
-      WS_FETCH_TABLE(ti + 1);                                 // the next task's codes arrived a task ago
-      if (A.stats) { st_tab += 3 * T; ++st_tasks; }
-      if (tid < cnt0) s_pool[tid] = my_key;
-      if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
-      if (tid == keep - 1 || (tid == 0 && cnt0 < keep)) ctl->thr = cnt0 >= keep ? my_key : kKeyInf;
-      ws_barrier();
-      WS_FETCH_CODES(ti + 2);
-      bool changed = false;
-      bool robust = cnt0 < keep;                             // no threshold yet: nothing can be left out
-      WS_CLOCK(1);
+      WS_FETCH_TABLE(g + kWsNW + wid);                        // next group: its codes arrived a group ago
+      if (A.stats && my_ti < n_tasks) { st_tab += 3 * my_T; ++st_tasks; }
 
-      for (;;) {                                           // again after an overflow (rare)
-        const unsigned long long thr = ctl->thr;
-        const uint32_t pool_at_start = ctl->pool_n;
-        const uint32_t need = matches_needed(thr, T, wbase);
-        if (min(T, wmt) < need) break;                     // (the threshold tightened in an earlier pass)
-        // ---- which dense slices are left out: the L largest, L <= need - cmin ------------------
-        const uint32_t l_max = (!robust && need > A.cmin) ? need - A.cmin : 0u;
-        const uint32_t size = tb0 - ta;
-        const bool dense = own && bm != kNoBitmap && size > 0;
-        uint32_t bigger = 0;
-        if (l_max)
-          for (unsigned long long m = __ballot(dense); m; m &= m - 1) {
-            const uint32_t u = __builtin_ctzll(m);
-            const uint32_t su = __builtin_amdgcn_readlane(size, u);
-            bigger += (su > size || (su == size && u < lane)) ? 1u : 0u;
+      for (uint32_t j = 0; j < kWsNW && g + j < n_tasks; ++j) {
+        const uint32_t ti = g + j;
+        const bool owner = wid == j;
+        const uint32_t q = s_task_q[ti];
+        const uint32_t meta = s_task_meta[ti];
+        const uint32_t T = meta & 0xFFu, cnt0 = meta >> 8;
+        // ---- the needle's state: its best keys so far ------------------------------------------
+        unsigned long long my_key = kKeyInf;
+        if (tid < cnt0) my_key = ws_load_key(A, q, tid);
+        if (tid < cnt0) s_pool[tid] = my_key;
+        if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
+        if (tid == keep - 1 || (tid == 0 && cnt0 < keep)) ctl->thr = cnt0 >= keep ? my_key : kKeyInf;
+        ws_barrier();
+        bool changed = false;
+        bool robust = cnt0 < keep;                           // no threshold yet: nothing can be left out
+        WS_CLOCK(1);
+
+        for (;;) {                                           // again after an overflow (rare)
+          const unsigned long long thr = ctl->thr;
+          const uint32_t pool_at_start = ctl->pool_n;
+          const uint32_t need = matches_needed(thr, T, wbase);
+          if (min(T, wmt) < need) break;                     // (the threshold tightened in an earlier pass)
+          // ---- owner: which dense slices are left out (the L largest, L <= need - cmin), which units
+          // are to be counted; published through s_units / s_hot / s_ctl.pub_* -------------------------
+          uint32_t o_tb = 0;                                 // owner's slice ends after leaving slices out
+          if (owner) {
+            const uint32_t l_max = (!robust && need > A.cmin) ? need - A.cmin : 0u;
+            const uint32_t size = tb0 - ta;
+            const bool dense = own && bm != kNoBitmap && size > 0;
+            uint32_t bigger = 0;
+            if (l_max)
+              for (unsigned long long m = __ballot(dense); m; m &= m - 1) {
+                const uint32_t u = __builtin_ctzll(m);
+                const uint32_t su = __builtin_amdgcn_readlane(size, u);
+                bigger += (su > size || (su == size && u < lane)) ? 1u : 0u;
+              }
+            const bool skip = dense && bigger < l_max;
+            const unsigned long long skipmask = __ballot(skip);
+            const uint32_t L = __popcll(skipmask);
+            if (skip) s_hot[__popcll(skipmask & ((1ull << lane) - 1ull))] = bm;
+            o_tb = skip ? ta : tb0;
+            // the units: slice t, 512 postings at a time; lane k keeps unit k
+            uint32_t nu = 0;
+            for (unsigned long long m = __ballot(o_tb > ta); m; m &= m - 1) {
+              const uint32_t t = __builtin_ctzll(m);
+              const uint32_t sa = __builtin_amdgcn_readlane(ta, t), sb = __builtin_amdgcn_readlane(o_tb, t);
+              const uint32_t su = slice_units(sa, sb);
+              if (nu + su <= 64) {
+                if (lane >= nu && lane < nu + su) s_units[lane] = make_uint2(sa + (lane - nu) * 512, sb);
+              }
+              nu += su;
+            }
+            if (nu > 64) {                                   // too many to list: publish the slice table instead,
+              s_units[lane] = make_uint2(ta, o_tb);          // every wave walks it (lane t: slice t)
+            }
+            if (lane == 0) {
+              s_ctl.pub_units = nu; s_ctl.pub_L = L;
+              s_ctl.pub_wide = min(T - L, wmt) > 15;         // a cold count could overflow four bits
+            }
           }
-        const bool skip = dense && bigger < l_max;
-        const unsigned long long skipmask = __ballot(skip);
-        const uint32_t L = __popcll(skipmask);
-        const uint32_t need_eff = need - L;                // >= cmin >= 1 when L > 0
-        const uint32_t tb = skip ? ta : tb0;
-        if (__ballot(tb > ta) == 0) break;                 // nothing to count: nothing can reach need_eff >= 1
-        const bool wide = min(T - L, wmt) > 15;            // a cold count could overflow four bits
-        ++st_steps;
-        WS_CLOCK(6);                                       // the left-out set chosen
+          ws_barrier();
+          const uint32_t n_units = s_ctl.pub_units, L = s_ctl.pub_L;
+          const bool wide = s_ctl.pub_wide != 0;
+          const uint32_t need_eff = need - L;                // >= cmin >= 1 when L > 0
+          if (n_units == 0) break;                           // nothing to count: nothing can reach need_eff >= 1
+          ++st_steps;
+          WS_CLOCK(6);                                       // the left-out set chosen, the units published
 
-        for (uint32_t h = 0; h < (wide ? 2u : 1u); ++h) {
-          // ---- count: this wave's units of the slices that are not left out.  The wave first lists its
-          // units -- lane k keeps unit k's (first entry, slice end) -- then streams them four at a time:
-          // four loads travel together, one memory round trip per four units, not one per unit. ----------
-          {
-            uint32_t my_c = 0, my_e = 0, nu = 0;
-            auto flush = [&]() {
-              for (uint32_t g = 0; g < nu; g += 4) {
+          for (uint32_t h = 0; h < (wide ? 2u : 1u); ++h) {
+            // ---- count: unit k belongs to wave k mod 4; four loads travel together ---------------------
+            if (n_units <= 64) {
+              for (uint32_t k0 = wid; k0 < n_units; k0 += 4 * kWsNW) {
                 uint4 u[4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                  const uint32_t c = __builtin_amdgcn_readlane(my_c, (g + j) & 63u);
-                  const uint32_t e = (g + j) < nu ? __builtin_amdgcn_readlane(my_e, (g + j) & 63u) : 0u;
-                  u[j] = load_group(A.ent, c + lane * 8, e);
-                  if (A.stats && (g + j) < nu) st_ent += min(512u, e - c);
+                for (uint32_t i = 0; i < 4; ++i) {
+                  const uint32_t k = k0 + i * kWsNW;
+                  const uint2 d = s_units[min(k, 63u)];
+                  const uint32_t c = __builtin_amdgcn_readfirstlane(d.x);
+                  const uint32_t e = k < n_units ? __builtin_amdgcn_readfirstlane(d.y) : 0u;
+                  u[i] = load_group(A.ent, c + lane * 8, e);
+                  if (A.stats && k < n_units) { st_ent += min(512u, e - c); ++st_units; }
                 }
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                  if (wide) ws_bump8<true>(s_cnt, u[j], h); else ws_bump8<false>(s_cnt, u[j], 0u);
+                for (uint32_t i = 0; i < 4; ++i) {
+                  if (wide) ws_bump8<true>(s_cnt, u[i], h); else ws_bump8<false>(s_cnt, u[i], 0u);
                 }
               }
-              nu = 0;
-            };
-            unsigned long long mask = __ballot(((wid - lane) & (kWsNW - 1)) < slice_units(ta, tb));
-            while (mask) {
-              const uint32_t t = __builtin_ctzll(mask);
-              mask &= mask - 1;
-              const uint32_t sa = __builtin_amdgcn_readlane(ta, t), sb = __builtin_amdgcn_readlane(tb, t);
-              const uint32_t su = slice_units(sa, sb);
-              for (uint32_t j = (wid - t) & (kWsNW - 1); j < su; j += kWsNW) {
-                if (lane == nu) { my_c = sa + j * 512; my_e = sb; }
-                if (++nu == 64) flush();
-              }
+            } else {
+              // the published slice table: this wave's units of every slice (unit i of slice t: wave (t + i) mod 4)
+              const uint2 d = s_units[lane];
+              const uint32_t xa = d.x, xb = d.y;
+              uint32_t k = 0;
+              uint4 pend = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
+              BLURRILY_FOR_SLOT_UNITS(kWsNW, xa, xb, wid, lane, k, {
+                const uint4 v = load_group(A.ent, c, sb);
+                if (A.stats) { st_ent += min(512u, sb - (c - lane * 8)); ++st_units; }
+                if (wide) ws_bump8<true>(s_cnt, pend, h); else ws_bump8<false>(s_cnt, pend, 0u);
+                pend = v;
+              });
+              if (wide) ws_bump8<true>(s_cnt, pend, h); else ws_bump8<false>(s_cnt, pend, 0u);
             }
-            flush();
+            WS_CLOCK(7);                                     // units loaded and counted
+            ws_barrier();
+            WS_CLOCK(2);                                     // barrier after the count
+            // ---- scan: counters that reach need_eff become candidates; everything is cleared -------
+            if (!robust) {
+              if (wide) ws_scan_fast<true>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, h, wlen);
+              else      ws_scan_fast<false>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, 0u, wlen);
+            } else {
+              uint32_t floor_need = need_eff;                // (== need: nothing is left out)
+              if (!wide && thr == kKeyInf && T > 1 && !A.tomb) {
+                // no threshold at all: admit only counters that can be among the best `keep` of this window
+                // alone (cold_start_need's argument), found by bisection over the counter value
+                uint32_t lo = 1, hi = min(T, 15u);
+                const uint32_t nv = WsLayout<false>(1u, 0u, wlen).nv;
+                while (lo < hi) {
+                  const uint32_t mid = (lo + hi + 1) >> 1;
+                  if (tid == 0) ctl->tally = 0;
+                  ws_barrier();
+                  const WsLayout<false> Y(mid, 0u, wlen);
+                  uint32_t mine = 0;
+                  for (uint32_t i = tid; i < nv; i += kWsNT) {
+                    const uint4 v = Y.mask_pad(cnt128[i], i);
+                    mine += __popc(Y.hits(v.x)) + __popc(Y.hits(v.y)) + __popc(Y.hits(v.z)) + __popc(Y.hits(v.w));
+                  }
+#pragma unroll
+                  for (uint32_t dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, int(dd));
+                  if (lane == 0 && mine) atomicAdd(&ctl->tally, mine);
+                  ws_barrier();
+                  if (ctl->tally >= keep) lo = mid; else hi = mid - 1;
+                  ws_barrier();
+                }
+                floor_need = max(floor_need, lo);
+              }
+              if (wide) ws_scan_robust<true>(A, cnt128, ctl, s_pool, thr, T, wbase, floor_need, h, wlen);
+              else      ws_scan_robust<false>(A, cnt128, ctl, s_pool, thr, T, wbase, min(floor_need, 16u), 0u, wlen);
+            }
+            // what no vector reached: the padding slot (short window), the dump word of the byte halves
+            if (tid == 0) {
+              const uint32_t nv_here = wide ? WsLayout<true>(1u, h, wlen).nv : WsLayout<false>(1u, 0u, wlen).nv;
+              if (nv_here < kWsCntWords / 4) s_cnt[kWsCntWords - 1] = 0;
+              if (wide) s_cnt[kWsCntWords] = 0;
+            }
+            ws_barrier();
+            WS_CLOCK(3);
           }
-          WS_CLOCK(7);                                     // units listed, loaded, counted
+          // ---- probe: the left-out slices' bitmaps give every candidate its exact match count.  A
+          // thread owns candidates tid and tid + 256; four slices' words travel together. ----------------
+          if (!robust && !s_ctl.cand_ov) {                   // (an overflowed list is abandoned: the robust pass redoes it all)
+            const uint32_t n_cand = s_ctl.n_cand;
+            if (A.stats && wid == 0) st_probe += n_cand * L;
+            const bool has0 = tid < n_cand, has1 = tid + kWsNT < n_cand;
+            const uint32_t c0 = has0 ? s_cand[tid] : 0u, c1 = has1 ? s_cand[tid + kWsNT] : 0u;
+            const uint32_t r0 = c0 & 0xFFFFu, r1 = c1 & 0xFFFFu;
+            uint32_t t0 = c0 >> 16, t1 = c1 >> 16;
+            if (__ballot(has0)) {
+              for (uint32_t i0 = 0; i0 < L; i0 += 4) {
+                uint32_t x0[4], x1[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                  x0[i] = x1[i] = 0;
+                  if (i0 + i < L) {                                        // (uniform)
+                    const uint32_t id = __builtin_amdgcn_readfirstlane(s_hot[i0 + i]);
+                    const uint32_t* bmw = A.bitmaps + size_t(id) * kBitmapWords;
+                    if (has0) x0[i] = bmw[r0 >> 5];
+                    if (has1) x1[i] = bmw[r1 >> 5];
+                  }
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) { t0 += (x0[i] >> (r0 & 31)) & 1u; t1 += (x1[i] >> (r1 & 31)) & 1u; }
+              }
+              if (has0) ws_admit(A, ctl, s_pool, thr, T, wbase, r0, t0);
+              if (has1) ws_admit(A, ctl, s_pool, thr, T, wbase, r1, t1);
+            }
+            ws_barrier();
+          }
+          WS_CLOCK(4);
+          // ---- select ---------------------------------------------------------------------------
+          const uint32_t cov = s_ctl.cand_ov;
+          const uint32_t ov = ctl->overflow | cov, pn = ctl->pool_n;
+          if (!ov && pn == pool_at_start) break;                           // nothing was admitted
           ws_barrier();
-          WS_CLOCK(2);                                     // barrier after the count
-          // ---- scan: counters that reach need_eff become candidates; everything is cleared -------
-          if (!robust) {
-            if (wide) ws_scan_fast<true>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, h, wlen);
-            else      ws_scan_fast<false>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, 0u, wlen);
-          } else {
-            uint32_t floor_need = need_eff;                // (== need: nothing is left out)
-            if (!wide && thr == kKeyInf && T > 1 && !A.tomb) {
-              // no threshold at all: admit only counters that can be among the best `keep` of this window
-              // alone (cold_start_need's argument), found by bisection over the counter value
-              uint32_t lo = 1, hi = min(T, 15u);
-              const uint32_t nv = (wlen + 31) / 32;
-              while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (tid == 0) ctl->tally = 0;
-                ws_barrier();
-                const WsLayout<false> Y(mid, 0u, wlen);
-                uint32_t mine = 0;
-                for (uint32_t i = tid; i < nv; i += kWsNT) {
-                  const uint4 v = Y.mask_pad(cnt128[i], i);
-                  mine += __popc(Y.hits(v.x)) + __popc(Y.hits(v.y)) + __popc(Y.hits(v.z)) + __popc(Y.hits(v.w));
-                }
-#pragma unroll
-                for (uint32_t dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, int(dd));
-                if (lane == 0 && mine) atomicAdd(&ctl->tally, mine);
-                ws_barrier();
-                if (ctl->tally >= keep) lo = mid; else hi = mid - 1;
-                ws_barrier();
-              }
-              floor_need = max(floor_need, lo);
-            }
-            if (wide) ws_scan_robust<true>(A, cnt128, ctl, s_pool, thr, T, wbase, floor_need, h, wlen);
-            else      ws_scan_robust<false>(A, cnt128, ctl, s_pool, thr, T, wbase, min(floor_need, 16u), 0u, wlen);
-          }
-          // what no vector reached: the padding slot (short window), the dump word of the byte halves
+          if (tid == 0) { s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
+          ++st_compact;
+          ws_compact_pool(s_pool, ctl, keep, pool_at_start);
+          changed = true;
+          if (!ov) break;
+          // An overflow: candidates of this window were lost.  Keep the tightened threshold, forget this
+          // window's survivors and sweep it again (every pass shrinks the admitted set) -- the robust way
+          // if it was the candidate list that overflowed.
+          ++st_redo;
+          if (cov) robust = true;
           if (tid == 0) {
-            const uint32_t nv_here = wide ? WsLayout<true>(1u, h, wlen).nv : WsLayout<false>(1u, 0u, wlen).nv;
-            if (nv_here < kWsCntWords / 4) s_cnt[kWsCntWords - 1] = 0;
-            if (wide) s_cnt[kWsCntWords] = 0;
-          }
-          ws_barrier();
-          WS_CLOCK(3);
-        }
-        // ---- probe: the left-out slices' bitmaps give every candidate its exact match count.  A
-        // thread owns candidates tid and tid + 256; four slices' words travel together. ----------------
-        if (!robust && !s_ctl.cand_ov) {                    // (an overflowed list is abandoned: the robust pass redoes it all)
-          const uint32_t n_cand = s_ctl.n_cand;
-          if (A.stats && wid == 0) st_probe += n_cand * L;
-          const bool has0 = tid < n_cand, has1 = tid + kWsNT < n_cand;
-          const uint32_t c0 = has0 ? s_cand[tid] : 0u, c1 = has1 ? s_cand[tid + kWsNT] : 0u;
-          const uint32_t r0 = c0 & 0xFFFFu, r1 = c1 & 0xFFFFu;
-          uint32_t t0 = c0 >> 16, t1 = c1 >> 16;
-          if (__ballot(has0)) {
-            unsigned long long m = skipmask;
-            while (m) {
-              uint32_t id[4], x0[4], x1[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                id[j] = kNoBitmap;
-                if (m) { id[j] = __builtin_amdgcn_readlane(bm, __builtin_ctzll(m)); m &= m - 1; }
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                x0[j] = x1[j] = 0;
-                if (id[j] != kNoBitmap) {                                  // (uniform)
-                  const uint32_t* bmw = A.bitmaps + size_t(id[j]) * kBitmapWords;
-                  if (has0) x0[j] = bmw[r0 >> 5];
-                  if (has1) x1[j] = bmw[r1 >> 5];
-                }
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { t0 += (x0[j] >> (r0 & 31)) & 1u; t1 += (x1[j] >> (r1 & 31)) & 1u; }
-            }
-            if (has0) ws_admit(A, ctl, s_pool, thr, T, wbase, r0, t0);
-            if (has1) ws_admit(A, ctl, s_pool, thr, T, wbase, r1, t1);
+            uint32_t jj = 0;
+            const uint32_t np = ctl->pool_n;
+            for (uint32_t i = 0; i < np; ++i)
+              if (uint32_t(s_pool[i]) - wbase >= wlen) s_pool[jj++] = s_pool[i];
+            ctl->pool_n = jj;
           }
           ws_barrier();
         }
-        WS_CLOCK(4);
-        // ---- select ---------------------------------------------------------------------------
-        const uint32_t cov = s_ctl.cand_ov;
-        const uint32_t ov = ctl->overflow | cov, pn = ctl->pool_n;
-        if (!ov && pn == pool_at_start) break;                           // nothing was admitted
+        // ---- write the state back if it changed --------------------------------------------------
         ws_barrier();
-        if (tid == 0) { s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
-        ++st_compact;
-        ws_compact_pool(s_pool, ctl, keep, pool_at_start);
-        changed = true;
-        if (!ov) break;
-        // An overflow: candidates of this window were lost.  Keep the tightened threshold, forget this
-        // window's survivors and sweep it again (every pass shrinks the admitted set) -- the robust way
-        // if it was the candidate list that overflowed.
-        ++st_redo;
-        if (cov) robust = true;
-        if (tid == 0) {
-          uint32_t j = 0;
-          const uint32_t np = ctl->pool_n;
-          for (uint32_t i = 0; i < np; ++i)
-            if (uint32_t(s_pool[i]) - wbase >= wlen) s_pool[j++] = s_pool[i];
-          ctl->pool_n = j;
+        if (changed) {
+          const uint32_t pn = ctl->pool_n;                                  // sorted, <= keep
+          uint32_t* st = reinterpret_cast<uint32_t*>(A.results + size_t(q) * A.limit);
+          if (tid < pn) {
+            const unsigned long long key = s_pool[tid];
+            st[2 * tid] = uint32_t(key); st[2 * tid + 1] = uint32_t(key >> 32);
+          }
+          if (tid == 0) A.counts[q] = pn;
         }
-        ws_barrier();
+        ws_barrier();                                        // pool and control quiet before the next task
+        WS_CLOCK(5);
       }
-      // ---- write the state back if it changed --------------------------------------------------
-      ws_barrier();
-      if (changed) {
-        const uint32_t pn = ctl->pool_n;                                  // sorted, <= keep
-        uint32_t* st = reinterpret_cast<uint32_t*>(A.results + size_t(q) * A.limit);
-        if (tid < pn) {
-          const unsigned long long key = s_pool[tid];
-          st[2 * tid] = uint32_t(key); st[2 * tid + 1] = uint32_t(key >> 32);
-        }
-        if (tid == 0) A.counts[q] = pn;
-      }
-      ws_barrier();                                     // pool and control quiet before the next task
-      WS_CLOCK(5);
+      WS_FETCH_CODES(g + 2 * kWsNW + wid);                   // the group after the next
     }
 #undef WS_FETCH_TABLE
 #undef WS_FETCH_CODES
   }
   if (A.stats && lane == 0) {
     atomicAdd(&A.stats[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    atomicAdd(&A.stats[kStatTableWords], static_cast<unsigned long long>(st_tab));
+    atomicAdd(&A.stats[kStatTasks], static_cast<unsigned long long>(st_tasks));
+    atomicAdd(&A.stats[kStatUnits], static_cast<unsigned long long>(st_units));
     if (wid == 0) {
       atomicAdd(&A.stats[kStatProbes], static_cast<unsigned long long>(st_probe));
-      atomicAdd(&A.stats[kStatTableWords], static_cast<unsigned long long>(st_tab) * kWsNW);
       atomicAdd(&A.stats[kStatSteps], static_cast<unsigned long long>(st_steps));
       atomicAdd(&A.stats[kStatResweeps], static_cast<unsigned long long>(st_redo));
-      atomicAdd(&A.stats[kStatTasks], static_cast<unsigned long long>(st_tasks));
       atomicAdd(&A.stats[kStatCompactions], static_cast<unsigned long long>(st_compact));
       for (int i = 0; i < 8; ++i) atomicAdd(&A.stats[kStatWsClocks + i], ws_clk[i]);
     }

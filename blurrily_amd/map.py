@@ -208,7 +208,7 @@ class RawMap:
         self._lib.blurrily_storage_set_timing(self._h, 1 if enabled else 0)
 
     STAT_NAMES = ("posting_entries", "steps", "table_words", "tasks", "compactions", "resweeps",
-                  "bitmap_words", "probes")
+                  "units", "probes")
 
     def set_stats(self, enabled):
         """Request counters of the find kernels on/off (include/blurrily_storage.h)."""

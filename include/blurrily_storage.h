@@ -170,7 +170,7 @@ void blurrily_storage_set_timing(trigram_map haystack, int enabled);
  *   [0] 16-bit postings loaded (x 2 = bytes; each is also one LDS-atomic lane)
  *   [1] sweep steps   [2] slice-table words loaded (x 4 = bytes)   [3] needles (or ranges) swept
  *   [4] candidate-pool compactions   [5] windows swept again after a pool overflow
- *   [6] bitmap words loaded (x 4 = bytes)   [7] candidate probes
+ *   [6] wave-loads of postings issued by the window-major sweep   [7] bitmap words read for its candidates
  * Collecting costs a few scalar instructions per wave-load; leave it off when timing. */
 void blurrily_storage_set_stats(trigram_map haystack, int enabled);
 int  blurrily_storage_find_stats(trigram_map haystack, uint64_t* out8);

@@ -1,54 +1,60 @@
 #!/usr/bin/env python3
-"""HBM-side traffic of the dominant find launch from the rocprofv3 --pmc passes that
-tools/collect_profiles.sh leaves in <dir>/pmc_{fetch,write,tcc}/ (sqlite output).
+"""Memory-side traffic of one bench step from the rocprofv3 --pmc passes that
+tools/collect_profiles.sh leaves in <dir>/pmc_{fetch,write,tcc}_<workload>/ (sqlite output).
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE
-and WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports half of a wide coalesced read stream.
-Infinity-Cache hits are included, so this is an upper bound on HBM bytes (the 247 MB posting
-array of the Geonames-scale index fits the 256 MiB Infinity Cache); TCC_EA0_RDREQ x 64 B is
-reported beside it as the lower reading.  Prints one JSON object."""
+and WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports half of a wide coalesced read stream.  They
+are the L2's memory-side (fabric) request counters: Infinity-Cache hits are included, so this bounds
+HBM bytes from above; TCC_EA0_RDREQ x 64 B is reported beside it.  Summed over every kernel of the find
+path (tokeniser, find_kernel, wsweep_kernel, finalize, merges) and divided by the number of find calls
+the profiled command makes (bench.py --steps 1 --warmup 0: the timed step and the counted one).
+Prints one JSON object: {workload: bytes per step, "detail": {...}}."""
 import glob
 import json
 import os
+import sqlite3
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from pmc_summary import summarise  # noqa: E402
+OURS = ("find_kernel", "wsweep_kernel", "tokenise", "finalize_rows", "merge_", "normalise", "apply_tombstones")
+CALLS_PER_RUN = 2
 
 
-def dominant(dirpath):
+def totals(dirpath):
     dbs = glob.glob(os.path.join(dirpath, "**", "*.db"), recursive=True)
     if not dbs:
-        return None, {}
-    per_kernel = summarise(dbs[0], only="find_kernel")
-    if not per_kernel:
-        return None, {}
-    # the launch that owns the time: largest max dispatch duration
-    name = max(per_kernel, key=lambda k: max(v[2] for v in per_kernel[k].values()))
-    return name, per_kernel[name]
+        return {}
+    c = sqlite3.connect(dbs[0])
+    rows = c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) "
+                     "from counters_collection group by kernel_name, counter_name").fetchall()
+    out, per_kernel = {}, {}
+    for k, n, v, disp in rows:
+        if not any(o in k for o in OURS):
+            continue
+        out[n] = out.get(n, 0.0) + v
+        short = k.replace("void ", "").replace("blurrily::(anonymous namespace)::", "").split("(")[0]
+        per_kernel.setdefault(short, {})[n] = [v, disp]
+    return {"sum": out, "per_kernel": per_kernel}
 
 
 def main():
     base = sys.argv[1]
-    out = {"_how": __doc__.split("\n\n")[1].replace("\n", " ")}
+    out = {"_how": " ".join(__doc__.split("\n\n")[1].split())}
     detail = {}
-    kname = None
-    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc"):
-        name, ctr = dominant(os.path.join(base, sub))
-        if name is None:
-            continue
-        kname = kname or name
-        for c, (v, disp, dur) in ctr.items():
-            detail[c] = v / max(disp, 1)                # per launch
-            detail.setdefault("dispatch_ns", dur)
-    detail["kernel"] = kname
-    if "FETCH_SIZE" in detail and "WRITE_SIZE" in detail:
-        out["geonames"] = (2 * detail["FETCH_SIZE"] + detail["WRITE_SIZE"]) * 1024
-        detail["fabric_TBps"] = out["geonames"] / (detail["dispatch_ns"] * 1e-9) / 1e12
-    if "TCC_EA0_RDREQ_sum" in detail:
-        detail["TCC_EA0_RDREQ_x64B"] = detail["TCC_EA0_RDREQ_sum"] * 64
-    if "TCC_HIT_sum" in detail and "TCC_MISS_sum" in detail:
-        detail["l2_hit_rate"] = detail["TCC_HIT_sum"] / (detail["TCC_HIT_sum"] + detail["TCC_MISS_sum"])
+    for wl in ("geonames", "words", "skewed"):
+        d = {}
+        for sub in ("fetch", "write", "tcc"):
+            t = totals(os.path.join(base, f"pmc_{sub}_{wl}"))
+            if t:
+                d.update({k: v / CALLS_PER_RUN for k, v in t["sum"].items()})
+                d.setdefault("per_kernel", {}).update(t["per_kernel"])
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            out[wl] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+        if "TCC_EA0_RDREQ_sum" in d:
+            d["TCC_EA0_RDREQ_x64B"] = d["TCC_EA0_RDREQ_sum"] * 64
+        if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
+            d["l2_hit_rate"] = d["TCC_HIT_sum"] / max(1.0, d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+        if d:
+            detail[wl] = d
     out["detail"] = detail
     print(json.dumps(out, indent=1))
 
