@@ -229,6 +229,11 @@ uint32_t ws_min_needles() { return env_u32("BLURRILY_WS_MIN_NEEDLES", 16384); }
 uint32_t ws_min_slice()   { return env_u32("BLURRILY_WS_MIN_SLICE", 3000); }
 constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for small host-buffer batches
 
+// the timed build of the kernels, or (while request counters are collected) the counted one
+int do_launch_find(bool counted_build, const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
+  return counted_build ? counted::launch_find(a, long_needles, grid, stream) : launch_find(a, long_needles, grid, stream);
+}
+
 // Enqueue tokenise + find for n device-resident needles.
 int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_total, const uint32_t* d_tomb,
                 const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n, uint16_t limit,
@@ -274,6 +279,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   a.floor = floor;
   a.tomb = d_tomb;
   a.stats = m->collect_stats ? m->d_stats : nullptr;
+  const bool cb = a.stats != nullptr;
 #ifdef BLURRILY_PHASE_PROFILE
   {
     static unsigned long long* d_phase = nullptr;
@@ -319,7 +325,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
       // (every task writes its part_count, also the ones the byte-counter kernel skips)
       a.short_only = 1;
-      if (launch_find(a, false, uint32_t(std::min<size_t>(tasks, wgs)), stream) < 0) return -1;
+      if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(tasks, wgs)), stream) < 0) return -1;
       uint32_t merge_cap = 1024;
       while (merge_cap < ranges * limit) merge_cap <<= 1;
       a.pool_cap = merge_cap;
@@ -329,7 +335,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
         a.pool_cap = find_pool_cap(a.keep);
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+        if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
     }
     // Large batches over many windows: the window-major sweep (find_kernels.hip, wsweep_kernel).
@@ -344,18 +350,19 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = ws_cmin();
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
       a.short_only = 1; a.own_only = 1;
-      if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+      if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       a.own_only = 0;
       for (uint32_t w = 0; w < ix.n_windows; ++w) {
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), stream) < 0) return -1;
+        if ((cb ? counted::launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), stream)
+                : launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), stream)) < 0) return -1;
       }
-      if (launch_finalize_rows(a, uint32_t(n), stream) < 0) return -1;
+      if ((cb ? counted::launch_finalize_rows(a, uint32_t(n), stream) : launch_finalize_rows(a, uint32_t(n), stream)) < 0) return -1;
       a.short_only = 0;
       if (maybe_mid) {                               // 65..127 distinct trigrams: needle-major, all windows
         a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+        if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
     }
     // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
@@ -366,12 +373,12 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
       const uint32_t grid = uint32_t(std::min<size_t>(n, wgs));
       a.short_only = 1;                              // needles with <= 64 distinct trigrams
-      if (launch_find(a, false, grid, stream) < 0) return -1;
+      if (do_launch_find(cb, a, false, grid, stream) < 0) return -1;
       a.short_only = 0;
       if (maybe_mid) {                               // 65..127: the tokeniser's mid list
         a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (launch_find(a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+        if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
     }
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
@@ -382,7 +389,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         a.pool_cap = 1024;
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
         const uint32_t grid = uint32_t(std::min<size_t>(n, size_t(m->n_cus)));
-        if (launch_find(a, true, grid, stream) < 0) return -1;
+        if (do_launch_find(cb, a, true, grid, stream) < 0) return -1;
       }
     }
   }

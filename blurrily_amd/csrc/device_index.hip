@@ -229,10 +229,12 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum; dense slices get a
   // bitmap number (in slice order: the image does not depend on thread timing)
   uint64_t n_slots = 0;
+  uint32_t dense_min = kDenseMin;                          // (BLURRILY_DENSE_MIN: tuning experiments)
+  if (const char* e = std::getenv("BLURRILY_DENSE_MIN")) dense_min = std::max(64u, uint32_t(std::atoi(e)));
   std::vector<uint32_t> bm_id(n_slices, kNoBitmap);
   uint32_t n_bitmaps = 0;
   for (uint64_t i = 0; i < n_slices; ++i) {
-    if (slice_off[i + 1] >= kDenseMin) bm_id[i] = n_bitmaps++;
+    if (slice_off[i + 1] >= dense_min) bm_id[i] = n_bitmaps++;
     const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
     n_slots += len;
     if (n_slots > 0xFFFF0000ull) { errno = EPROTO; return -1; }

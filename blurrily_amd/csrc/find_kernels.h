@@ -104,6 +104,13 @@ int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hip
 // Turn the needles' states (keys) into result rows, in place.
 int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream);
 constexpr uint32_t kWsMaxKeep = 128;   // largest limit the window-major sweep serves
+
+// the same launches of the build that keeps FindArgs::stats (find_kernels_counted.hip)
+namespace counted {
+int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
+int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hipStream_t stream);
+int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream);
+}
 // Merge, per needle, two result lists that are each in result order (base image and delta image
 // hold disjoint references) into the first `limit` rows of `out`.
 int launch_merge_rows(const trigram_match_t* a_rows, const uint32_t* a_counts, const trigram_match_t* b_rows,

@@ -44,7 +44,23 @@
 #include <cstdlib>
 #include <type_traits>
 
+// This file is compiled twice (csrc/Makefile): as it is -- the kernels that are timed, with no trace of
+// the request counters -- and through find_kernels_counted.hip with BLURRILY_COUNTED defined, into
+// namespace blurrily::counted: the same kernels keeping FindArgs::stats (blurrily_storage_set_stats).
+// (Counting behind a run-time `if (A.stats)` cost the needle-major kernel 7 %: registers and branches
+// in its innermost loops, measured on one box, tools/ab_probe.py.)
+#ifdef BLURRILY_COUNTED
+#define STATS(A) ((A).stats)
+#define BLURRILY_KERNELS_BEGIN namespace counted {
+#define BLURRILY_KERNELS_END }
+#else
+#define STATS(A) (static_cast<unsigned long long*>(nullptr))
+#define BLURRILY_KERNELS_BEGIN
+#define BLURRILY_KERNELS_END
+#endif
+
 namespace blurrily {
+BLURRILY_KERNELS_BEGIN
 
 namespace {
 
@@ -647,7 +663,7 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
   // compact when the pool fills up -- or as soon as it holds `keep` candidates for the first
   // time, so that a threshold exists from then on
   if (!(ov || pn > A.pool_cap / 2 || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
-  if (A.stats && threadIdx.x == 0) atomicAdd(&A.stats[kStatCompactions], 1ull);
+  if (STATS(A) && threadIdx.x == 0) atomicAdd(&STATS(A)[kStatCompactions], 1ull);
   compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
   if (!ov) return false;
   // The pool overflowed mid-window: candidates of this window were lost.  Keep the
@@ -685,7 +701,7 @@ __device__ __forceinline__ bool count_window(const FindArgs& A, uint32_t* cnt32,
     const uint32_t su = slice_units(a, b);
     for (uint32_t j = (wid - t) & (kNW - 1); j < su; j += kNW) {
       const uint4 v = load_group(A.ent, a + (j * 64 + lane) * 8, b);
-      stat_unit(A.stats, v);
+      stat_unit(STATS(A), v);
       bump8<CT>(cnt32, v);
     }
   }
@@ -865,15 +881,15 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
       // ---- count window w: its head was loaded one window ago ---------------------------
       PHASE_UNIT(u0); PHASE_UNIT(u1); PHASE_UNIT(u2);
       if (KP > 3) PHASE_UNIT(u3);
-      stat_unit(A.stats, u0); stat_unit(A.stats, u1); stat_unit(A.stats, u2);
-      if (KP > 3) stat_unit(A.stats, u3);
-      if (A.stats && tid == 0) atomicAdd(&A.stats[kStatSteps], 1ull);
+      stat_unit(STATS(A), u0); stat_unit(STATS(A), u1); stat_unit(STATS(A), u2);
+      if (KP > 3) stat_unit(STATS(A), u3);
+      if (STATS(A) && tid == 0) atomicAdd(&STATS(A)[kStatSteps], 1ull);
       bump8<CT>(cnt32, u0);
       bump8<CT>(cnt32, u1);
       bump8<CT>(cnt32, u2);
       if (KP > 3) bump8<CT>(cnt32, u3);
       PHASE_MARK(1);                                            // head counted
-      if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre, A.stats);
+      if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre, STATS(A));
       PHASE_MARK(2);                                            // rest counted
       __syncthreads();                                          // counts visible
       PHASE_MARK(3);                                            // barrier after count
@@ -894,7 +910,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
         if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
-        count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u, A.stats);   // overflow: again
+        count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u, STATS(A));   // overflow: again
         __syncthreads();
       }
       PHASE_MARK(7);                                            // select / compaction
@@ -967,7 +983,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   do {                                                                           \
     A0 = B0 = A1 = B1 = 0;                                                       \
     const uint32_t w_ = (p_) * kWPS;                                             \
-    if (A.stats && w_ < w1) st_tab += 2u * tc * (kNib && w_ + 1 < w1 ? 2u : 1u); \
+    if (STATS(A) && w_ < w1) st_tab += 2u * tc * (kNib && w_ + 1 < w1 ? 2u : 1u); \
     if (w_ < w1 && own) {                                                        \
       const uint32_t idx_ = w_ * kNumCodes + code;                               \
       A0 = A.slice_off[idx_]; B0 = A.slice_off[idx_ + 1];                        \
@@ -1007,7 +1023,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                    \
     H = x_ & 1u;                                                                 \
     U = load_group(A.ent, (x_ & ~7u) + lane * 8, y_);                            \
-    if (A.stats) st_ent += min(512u, y_ - (x_ & ~7u));                           \
+    if (STATS(A)) st_ent += min(512u, y_ - (x_ & ~7u));                           \
   } while (0)
   // the units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
   // atomics run while the next unit's load is in flight
@@ -1030,11 +1046,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     BLURRILY_FETCH_TABLE(p_, fa0_, fb0_, fa1_, fb1_);                            \
     BLURRILY_FOR_SLOT_UNITS(kNW, fa0_, fb0_, wid, lane, k_,                      \
                             { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 0u);   \
-                              if (A.stats) st_ent += min(512u, sb - (c - lane * 8)); }); \
+                              if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
     if (kNib)                                                                    \
       BLURRILY_FOR_SLOT_UNITS(kNW, fa1_, fb1_, wid, lane, k_,                    \
                               { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); \
-                                if (A.stats) st_ent += min(512u, sb - (c - lane * 8)); }); \
+                                if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
   } while (0)
 #if BLURRILY_COOP_ROTATE
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
@@ -1099,12 +1115,12 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     i_next = i_next2;
   }
   PHASE_FLUSH(A);
-  if (A.stats && lane == 0) {
-    atomicAdd(&A.stats[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
-    atomicAdd(&A.stats[kStatTableWords], static_cast<unsigned long long>(st_tab));
+  if (STATS(A) && lane == 0) {
+    atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
     if (wid == 0) {
-      atomicAdd(&A.stats[kStatSteps], static_cast<unsigned long long>(st_steps));
-      atomicAdd(&A.stats[kStatResweeps], static_cast<unsigned long long>(st_redo));
+      atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
+      atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
     }
   }
   __syncthreads();                                              // ring and ctl quiet before the needle ends
@@ -1196,7 +1212,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     __syncthreads();
 
     PHASE_NEEDLE(10);
-    if (A.stats && tid == 0) atomicAdd(&A.stats[kStatTasks], 1ull);
+    if (STATS(A) && tid == 0) atomicAdd(&STATS(A)[kStatTasks], 1ull);
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
@@ -1653,7 +1669,7 @@ __device__ __forceinline__ void ws_scan_robust(const FindArgs& A, uint4* cnt128,
 }
 
 // phase clocks of wave 0 (stats mode only): FindArgs::stats[kStatWsClocks + phase]
-#define WS_CLOCK(i) do { if (A.stats && wid == 0) { const unsigned long long t_ = clock64(); ws_clk[i] += t_ - ws_last; ws_last = t_; } } while (0)
+#define WS_CLOCK(i) do { if (STATS(A) && wid == 0) { const unsigned long long t_ = clock64(); ws_clk[i] += t_ - ws_last; ws_last = t_; } } while (0)
 
 __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, const uint32_t w, const uint32_t n,
                                                           const uint32_t chunk_len) {
@@ -1738,7 +1754,7 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
       const bool own = lane < my_T;
       const uint32_t ta = nx_ta, tb0 = nx_tb, bm = nx_bm;     // (waits for the prefetched table)
       WS_FETCH_TABLE(g + kWsNW + wid);                        // next group: its codes arrived a group ago
-      if (A.stats && my_ti < n_tasks) { st_tab += 3 * my_T; ++st_tasks; }
+      if (STATS(A) && my_ti < n_tasks) { st_tab += 3 * my_T; ++st_tasks; }
 
       for (uint32_t j = 0; j < kWsNW && g + j < n_tasks; ++j) {
         const uint32_t ti = g + j;
@@ -1820,7 +1836,7 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
                   const uint32_t c = __builtin_amdgcn_readfirstlane(d.x);
                   const uint32_t e = k < n_units ? __builtin_amdgcn_readfirstlane(d.y) : 0u;
                   u[i] = load_group(A.ent, c + lane * 8, e);
-                  if (A.stats && k < n_units) { st_ent += min(512u, e - c); ++st_units; }
+                  if (STATS(A) && k < n_units) { st_ent += min(512u, e - c); ++st_units; }
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < 4; ++i) {
@@ -1835,7 +1851,7 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
               uint4 pend = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
               BLURRILY_FOR_SLOT_UNITS(kWsNW, xa, xb, wid, lane, k, {
                 const uint4 v = load_group(A.ent, c, sb);
-                if (A.stats) { st_ent += min(512u, sb - (c - lane * 8)); ++st_units; }
+                if (STATS(A)) { st_ent += min(512u, sb - (c - lane * 8)); ++st_units; }
                 if (wide) ws_bump8<true>(s_cnt, pend, h); else ws_bump8<false>(s_cnt, pend, 0u);
                 pend = v;
               });
@@ -1890,7 +1906,7 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
           // thread owns candidates tid and tid + 256; four slices' words travel together. ----------------
           if (!robust && !s_ctl.cand_ov) {                   // (an overflowed list is abandoned: the robust pass redoes it all)
             const uint32_t n_cand = s_ctl.n_cand;
-            if (A.stats && wid == 0) st_probe += n_cand * L;
+            if (STATS(A) && wid == 0) st_probe += n_cand * L;
             const bool has0 = tid < n_cand, has1 = tid + kWsNT < n_cand;
             const uint32_t c0 = has0 ? s_cand[tid] : 0u, c1 = has1 ? s_cand[tid + kWsNT] : 0u;
             const uint32_t r0 = c0 & 0xFFFFu, r1 = c1 & 0xFFFFu;
@@ -1960,17 +1976,17 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
 #undef WS_FETCH_TABLE
 #undef WS_FETCH_CODES
   }
-  if (A.stats && lane == 0) {
-    atomicAdd(&A.stats[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
-    atomicAdd(&A.stats[kStatTableWords], static_cast<unsigned long long>(st_tab));
-    atomicAdd(&A.stats[kStatTasks], static_cast<unsigned long long>(st_tasks));
-    atomicAdd(&A.stats[kStatUnits], static_cast<unsigned long long>(st_units));
+  if (STATS(A) && lane == 0) {
+    atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
+    atomicAdd(&STATS(A)[kStatTasks], static_cast<unsigned long long>(st_tasks));
+    atomicAdd(&STATS(A)[kStatUnits], static_cast<unsigned long long>(st_units));
     if (wid == 0) {
-      atomicAdd(&A.stats[kStatProbes], static_cast<unsigned long long>(st_probe));
-      atomicAdd(&A.stats[kStatSteps], static_cast<unsigned long long>(st_steps));
-      atomicAdd(&A.stats[kStatResweeps], static_cast<unsigned long long>(st_redo));
-      atomicAdd(&A.stats[kStatCompactions], static_cast<unsigned long long>(st_compact));
-      for (int i = 0; i < 8; ++i) atomicAdd(&A.stats[kStatWsClocks + i], ws_clk[i]);
+      atomicAdd(&STATS(A)[kStatProbes], static_cast<unsigned long long>(st_probe));
+      atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
+      atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
+      atomicAdd(&STATS(A)[kStatCompactions], static_cast<unsigned long long>(st_compact));
+      for (int i = 0; i < 8; ++i) atomicAdd(&STATS(A)[kStatWsClocks + i], ws_clk[i]);
     }
   }
 }
@@ -2159,4 +2175,5 @@ int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t
   return launch_find_t<uint16_t, 1024>(a, grid, stream);
 }
 
+BLURRILY_KERNELS_END
 }  // namespace blurrily

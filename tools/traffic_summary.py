@@ -46,7 +46,8 @@ def main():
             t = totals(os.path.join(base, f"pmc_{sub}_{wl}"))
             if t:
                 d.update({k: v / CALLS_PER_RUN for k, v in t["sum"].items()})
-                d.setdefault("per_kernel", {}).update(t["per_kernel"])
+                for k, ctr in t["per_kernel"].items():
+                    d.setdefault("per_kernel", {}).setdefault(k, {}).update(ctr)
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             out[wl] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
         if "TCC_EA0_RDREQ_sum" in d:
