@@ -123,11 +123,26 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   n_threads = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(n_threads, nnz / 32768)));
   if (lead == host.total_refs()) {
     refs.reserve(lead);
+    uint32_t hi_ref = 0;
     for (uint32_t s = 0; s + 1 < uint32_t(kBase); ++s) {
       const Bucket& bk = host.bucket(s * kBase * kBase);
       refs.insert(refs.end(), bk.e, bk.e + bk.used);
+      for (uint32_t j = 0; j < bk.used; ++j) hi_ref = std::max(hi_ref, bk.e[j].ref);
     }
-    parallel_sort(refs, n_threads, [](const Entry& l, const Entry& r) { return l.ref < r.ref; }, false);
+    if (!refs.empty() && uint64_t(hi_ref) < 4ull * refs.size() + 1024) {
+      // references dense in their range (1..N, the usual case): place them instead of sorting them
+      std::vector<uint32_t> weight_at(size_t(hi_ref) + 1);
+      std::vector<uint8_t> seen(size_t(hi_ref) + 1, 0);
+      for (const Entry& e : refs) {
+        if (seen[e.ref]) { errno = EPROTO; return -1; }               // a reference listed twice
+        seen[e.ref] = 1; weight_at[e.ref] = e.weight;
+      }
+      size_t k = 0;
+      for (uint32_t r = 0; r <= hi_ref; ++r)
+        if (seen[r]) { refs[k].ref = r; refs[k].weight = weight_at[r]; ++k; }
+    } else {
+      parallel_sort(refs, n_threads, [](const Entry& l, const Entry& r) { return l.ref < r.ref; }, false);
+    }
   } else {
     refs.reserve(nnz);
     for (uint32_t t = 0; t < kNumCodes; ++t) {
@@ -153,9 +168,21 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   std::vector<uint32_t> ref_of_rank(n_refs), weight_of_rank(n_refs);
   {
     std::vector<uint32_t> order(n_refs);
-    for (uint32_t i = 0; i < n_refs; ++i) { order[i] = i; sorted_ref[i] = refs[i].ref; }
-    parallel_sort(order, n_threads,                                // refs[] is ref-ascending: a stable
-                  [&](uint32_t l, uint32_t r) { return refs[l].weight < refs[r].weight; }, true);   // sort by weight
+    uint32_t w_lo = 0xFFFFFFFFu, w_hi = 0;
+    for (uint32_t i = 0; i < n_refs; ++i) {
+      order[i] = i; sorted_ref[i] = refs[i].ref;
+      w_lo = std::min(w_lo, refs[i].weight); w_hi = std::max(w_hi, refs[i].weight);
+    }
+    if (n_refs && uint64_t(w_hi) - w_lo < (1u << 20)) {
+      // weights in a narrow range (string lengths, the default): a counting sort, stable by construction
+      std::vector<uint32_t> at(size_t(w_hi - w_lo) + 2, 0);
+      for (uint32_t i = 0; i < n_refs; ++i) at[refs[i].weight - w_lo + 1] += 1;
+      for (size_t k = 1; k < at.size(); ++k) at[k] += at[k - 1];
+      for (uint32_t i = 0; i < n_refs; ++i) order[at[refs[i].weight - w_lo]++] = i;
+    } else {
+      parallel_sort(order, n_threads,                              // refs[] is ref-ascending: a stable
+                    [&](uint32_t l, uint32_t r) { return refs[l].weight < refs[r].weight; }, true);   // sort by weight
+    }
     for (uint32_t rk = 0; rk < n_refs; ++rk) {
       const uint32_t pos = order[rk];
       rank_of_pos[pos] = rk;
@@ -195,12 +222,35 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     for (auto& th : pool) th.join();
   };
 
+  // References that are dense in their range (1..N, the usual case) are ranked through a direct table:
+  // one load per posting instead of a galloping search (Geonames scale: 1.3 s -> a fifth of that).
+  std::vector<uint32_t> rank_by_ref;
+  const uint32_t max_ref = n_refs ? sorted_ref[n_refs - 1] : 0u;
+  const bool dense_refs = n_refs > 0 && uint64_t(max_ref) < 4ull * n_refs + 1024;
+  if (dense_refs) {
+    rank_by_ref.assign(size_t(max_ref) + 1, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < n_refs; ++i) rank_by_ref[sorted_ref[i]] = rank_of_pos[i];
+  }
   parallel_codes([&](uint32_t t) {
     const Bucket& bk = host.bucket(t);
     if (!bk.used) return;
     std::vector<Entry> scratch;
     const Entry* e = sorted_view(bk, scratch);
     uint32_t* out_rank = rank.data() + bucket_base[t];
+    if (dense_refs) {
+      for (uint32_t j = 0; j < bk.used; ++j) {
+        const uint32_t ref = e[j].ref;
+        const uint32_t rk = ref <= max_ref ? rank_by_ref[ref] : 0xFFFFFFFFu;
+        // a reference missing from the table, listed twice in the bucket, or with a second weight
+        if (rk == 0xFFFFFFFFu || (j > 0 && e[j - 1].ref >= ref) || weight_of_rank[rk] != e[j].weight) {
+          failed.store(1);
+          return;
+        }
+        out_rank[j] = rk;
+        slice_off[uint64_t(rk / kWindowRanks) * kNumCodes + t + 1] += 1;
+      }
+      return;
+    }
     uint64_t pos = 0;                         // references ascend inside a bucket: gallop from the last hit
     for (uint32_t j = 0; j < bk.used; ++j) {
       const uint32_t ref = e[j].ref;

@@ -84,6 +84,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_COOP_ROTATE
 #define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
 #endif
+#ifndef BLURRILY_NEXT_BEFORE_BARRIER
+#define BLURRILY_NEXT_BEFORE_BARRIER 1 // sweep_coop: the step after the next is chosen before the count barrier, not after
+#endif
 #ifndef BLURRILY_HEAD_UNITS
 #define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
 #endif
@@ -1092,11 +1095,20 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       else if (lane == 0) ring->n_units[s ^ 1u] = 0;
     }
     PHASE_MARK(7);                                              // (producer turn) next step's units published
+#if BLURRILY_NEXT_BEFORE_BARRIER
+    // ---- decide the step after the next BEFORE the barrier: the threshold only changes behind select's
+    // barriers, so the answer is the same, and the window-bound load and the table fetch travel under
+    // the wait for the slowest wave instead of standing between the barrier and the scan ----------
+    BLURRILY_NEXT_VISIT(i_next + 1, i_next2);
+    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb, ta1, tb1);
+#endif
     __syncthreads();                                            // counts and next descriptors visible
     PHASE_MARK(3);                                              // barrier after count
+#if !BLURRILY_NEXT_BEFORE_BARRIER
     // ---- decide the step after the next; its table travels during the scan -------------------
     BLURRILY_NEXT_VISIT(i_next + 1, i_next2);                   // uniform: thr only changes behind select's barriers
     if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb, ta1, tb1);
+#endif
     PHASE_MARK(4);                                              // step after the next chosen
     if (n_units) {
       for (;;) {
