@@ -127,3 +127,25 @@ def test_oracle_vs_live_reference_hypothesis(entries, needle, limit):
         for s, _ in entries[:5]:
             assert o.find(s, limit) == ref.find(s, limit)
         ref.close()
+
+
+def test_batch_driver_equals_single_calls():
+    """oracle/oracle_batch.c (the threaded driver the full-size GPU checks use) is exactly one
+    oracle_find / oracle_nb_entries / oracle_tokenise per element."""
+    import numpy as np
+    import workloads as W
+    hay, off = W.geonames(20000, 3000, 7)
+    o = Oracle()
+    o.put_many(hay, off)
+    q, qo = W.queries(hay, off, 300, 8)
+    needles = W.unpack(q, qo)
+    idx = np.arange(0, 300, 3, dtype=np.uint32)
+    for threads in (1, 4):
+        got = o.batch(q, qo, idx=idx, limit=7, nb=True, ntri=True, threads=threads)
+        for k, i in enumerate(idx):
+            nd = needles[int(i)]
+            assert got["rows"][k, :got["counts"][k]].tolist() == o.find(nd, 7)
+            assert int(got["nb"][k]) == o.nb_entries(nd)
+            assert int(got["ntri"][k]) == len(Oracle.tokenise(nd))
+    every = o.batch(q, qo, find=False, nb=True)
+    assert [int(v) for v in every["nb"]] == [o.nb_entries(nd) for nd in needles]
