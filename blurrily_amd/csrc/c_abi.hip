@@ -348,14 +348,19 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
       a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = ws_cmin();
+      // Phase 1: the needle-major kernel over the window pair of every needle's own length class seeds the
+      // states (a needle's best matches live there, so its threshold is tight before the other windows are
+      // visited).  (Seeding through wsweep_kernel's own robust path instead -- own_pass launches -- was
+      // measured: configs[2] 321 -> 355 ms per 300 k needles, configs[4] 82 -> 129 ms: without a threshold
+      // the 4-wave task floods its pool again and again where the 16-wave kernel bisects once.)
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
       a.short_only = 1; a.own_only = 1;
       if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       a.own_only = 0;
       for (uint32_t w = 0; w < ix.n_windows; ++w) {
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if ((cb ? counted::launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), stream)
-                : launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), stream)) < 0) return -1;
+        if ((cb ? counted::launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), false, stream)
+                : launch_wsweep(a, w, uint32_t(n), uint32_t(m->n_cus), false, stream)) < 0) return -1;
       }
       if ((cb ? counted::launch_finalize_rows(a, uint32_t(n), stream) : launch_finalize_rows(a, uint32_t(n), stream)) < 0) return -1;
       a.short_only = 0;

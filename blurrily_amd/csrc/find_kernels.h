@@ -98,9 +98,10 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
                      hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
-// Window-major sweep of window `w` over needles [0, n) (those with <= 64 distinct trigrams whose state
-// find_kernel left with own_only set); a.queue must be a zeroed word of its own.
-int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hipStream_t stream);
+// Window-major sweep of window `w` over needles [0, n) (those with <= 64 distinct trigrams); a.queue must
+// be a zeroed word of its own.  own_pass: only the needles whose own length class lives in this window
+// pair -- the launches that seed the states (counts[] zeroed before the first of them); else the others.
+int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, bool own_pass, hipStream_t stream);
 // Turn the needles' states (keys) into result rows, in place.
 int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream);
 constexpr uint32_t kWsMaxKeep = 128;   // largest limit the window-major sweep serves
@@ -108,7 +109,7 @@ constexpr uint32_t kWsMaxKeep = 128;   // largest limit the window-major sweep s
 // the same launches of the build that keeps FindArgs::stats (find_kernels_counted.hip)
 namespace counted {
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
-int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hipStream_t stream);
+int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, bool own_pass, hipStream_t stream);
 int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream);
 }
 // Merge, per needle, two result lists that are each in result order (base image and delta image

@@ -1694,6 +1694,18 @@ __device__ __forceinline__ void ws_scan_fast(uint4* cnt128, uint32_t* cand, uint
   }
 }
 
+// counters of this thread's vectors that reach `need` (nothing is cleared): the cold-start bisection
+template <bool WIDE>
+__device__ __forceinline__ uint32_t ws_count_hits(const uint4* cnt128, uint32_t need, uint32_t h, uint32_t wlen) {
+  const WsLayout<WIDE> Y(need, h, wlen);
+  uint32_t mine = 0;
+  for (uint32_t i = threadIdx.x; i < Y.nv; i += kWsNT) {
+    const uint4 v = Y.mask_pad(cnt128[i], i);
+    mine += __popc(Y.hits(v.x)) + __popc(Y.hits(v.y)) + __popc(Y.hits(v.z)) + __popc(Y.hits(v.w));
+  }
+  return mine;
+}
+
 // Robust scan (no threshold yet, or a candidate list that overflowed): nothing is left out of the count,
 // so a counter IS the match count and a hit goes straight to the pool if its key beats the threshold --
 // only such hits take room, so a flood of ties behind the threshold's rank cannot fill anything.
@@ -1725,7 +1737,7 @@ __device__ __forceinline__ void ws_scan_robust(const FindArgs& A, uint4* cnt128,
 #define WS_CLOCK(i) do { if (STATS(A) && wid == 0) { const unsigned long long t_ = clock64(); ws_clk[i] += t_ - ws_last; ws_last = t_; } } while (0)
 
 __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, const uint32_t w, const uint32_t n,
-                                                          const uint32_t chunk_len) {
+                                                          const uint32_t chunk_len, const uint32_t own_pass) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];       // + dump word
   __shared__ uint32_t s_cand[kWsCand];
   __shared__ unsigned long long s_pool[kWsPool];
@@ -1760,7 +1772,9 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
       bool live = q < n && tid < chunk_len;
       uint32_t T = 0, cnt = 0, need = 0;
       if (live) { T = A.q_ntri[q]; live = T <= 64 && A.q_nb[q] != 0; }
-      if (live) { const uint32_t own0 = A.q_start[q] & ~1u; live = !(w >= own0 && w < own0 + 2); }   // phase 1 did those
+      // own_pass: only the needles whose own length class lives in this window pair (their first two tasks,
+      // which give them a threshold); otherwise everybody else
+      if (live) { const uint32_t own0 = A.q_start[q] & ~1u; live = (w >= own0 && w < own0 + 2) == (own_pass != 0); }
       if (live) {
         cnt = A.counts[q];
         const unsigned long long thr = cnt >= keep ? ws_load_key(A, q, keep - 1) : kKeyInf;
@@ -1919,21 +1933,15 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
               else      ws_scan_fast<false>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, 0u, wlen);
             } else {
               uint32_t floor_need = need_eff;                // (== need: nothing is left out)
-              if (!wide && thr == kKeyInf && T > 1 && !A.tomb) {
+              if (thr == kKeyInf && T > 1 && !A.tomb) {
                 // no threshold at all: admit only counters that can be among the best `keep` of this window
-                // alone (cold_start_need's argument), found by bisection over the counter value
-                uint32_t lo = 1, hi = min(T, 15u);
-                const uint32_t nv = WsLayout<false>(1u, 0u, wlen).nv;
+                // (or half of it) alone (cold_start_need's argument), found by bisection over the counter value
+                uint32_t lo = 1, hi = min(T, wide ? 127u : 15u);
                 while (lo < hi) {
                   const uint32_t mid = (lo + hi + 1) >> 1;
                   if (tid == 0) ctl->tally = 0;
                   ws_barrier();
-                  const WsLayout<false> Y(mid, 0u, wlen);
-                  uint32_t mine = 0;
-                  for (uint32_t i = tid; i < nv; i += kWsNT) {
-                    const uint4 v = Y.mask_pad(cnt128[i], i);
-                    mine += __popc(Y.hits(v.x)) + __popc(Y.hits(v.y)) + __popc(Y.hits(v.z)) + __popc(Y.hits(v.w));
-                  }
+                  uint32_t mine = wide ? ws_count_hits<true>(cnt128, mid, h, wlen) : ws_count_hits<false>(cnt128, mid, 0u, wlen);
 #pragma unroll
                   for (uint32_t dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, int(dd));
                   if (lane == 0 && mine) atomicAdd(&ctl->tally, mine);
@@ -2169,7 +2177,7 @@ int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) 
   return 0;
 }
 
-int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hipStream_t stream) {
+int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, bool own_pass, hipStream_t stream) {
   if (n == 0) return 0;
   // needles per queue pop: whole 256-thread filters for big batches, smaller chunks when there are too
   // few needles to give every resident workgroup (four per CU) several chunks
@@ -2177,7 +2185,7 @@ int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, hip
   while (chunk_len > 16 && (n + chunk_len - 1) / chunk_len < n_cus * 4u * 4u) chunk_len >>= 1;
   const uint32_t chunks = (n + chunk_len - 1) / chunk_len;
   const uint32_t grid = std::min(chunks, n_cus * 4u);
-  hipLaunchKernelGGL(wsweep_kernel, dim3(grid), dim3(kWsNT), 0, stream, a, w, n, chunk_len);
+  hipLaunchKernelGGL(wsweep_kernel, dim3(grid), dim3(kWsNT), 0, stream, a, w, n, chunk_len, own_pass ? 1u : 0u);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }
