@@ -92,6 +92,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
                                        // (measured, same box: 391.2 vs 379.7 ms per 500 k needles -- 3 % SLOWER than the
                                        // lane-wise ds_write_b128: the LDS store path is not what the step waits for)
 #endif
+#ifndef BLURRILY_SCAN_PREFILTER
+#define BLURRILY_SCAN_PREFILTER 1      // the scan tests a vector with one AND before the exact SWAR test
+#endif
 #ifndef BLURRILY_HEAD_UNITS
 #define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
 #endif
@@ -343,8 +346,14 @@ template <typename CT> struct ScanTraits {
   using P = Packing<CT>;
   static constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
   static constexpr uint32_t kMaxCount = P::kTop - 1;
-  struct Need { uint32_t bias; };
-  static __device__ __forceinline__ Need prepare(uint32_t need) { return Need{(P::kTop - need) * P::kOnes}; }
+  struct Need { uint32_t bias, pre; };
+  // pre: a counter >= need >= 2^k has one of the bits k.. of its field set -- one AND per vector tells
+  // whether any counter can reach `need` at all before the exact test
+  static __device__ __forceinline__ Need prepare(uint32_t need) {
+    const uint32_t top = 31u - __clz(max(need, 1u));
+    return Need{(P::kTop - need) * P::kOnes, P::kOnes * ((P::kMask << top) & P::kMask)};
+  }
+  static __device__ __forceinline__ bool maybe(uint4 v, Need n) { return ((v.x | v.y | v.z | v.w) & n.pre) != 0; }
   static __device__ __forceinline__ uint32_t hits(uint32_t v, Need n) { return (v + n.bias) & P::kHi; }
   static __device__ __forceinline__ uint32_t any_hit(uint4 v, Need n) {
     return ((v.x + n.bias) | (v.y + n.bias) | (v.z + n.bias) | (v.w + n.bias)) & P::kHi;
@@ -366,10 +375,13 @@ template <> struct ScanTraits<Nib> {
   static constexpr uint32_t kMaxCount = 15;
   // counter >= need, with c = counter, lo = c & 7:  need <= 8: c >= 8 or lo + (8 - need) >= 8;
   //                                                 need >  8: c >= 8 and lo + (16 - need) >= 8
-  struct Need { uint32_t bias; bool low; };
+  struct Need { uint32_t bias; bool low; uint32_t pre; };
   static __device__ __forceinline__ Need prepare(uint32_t need) {
-    return need <= 8 ? Need{(8 - need) * 0x11111111u, true} : Need{(16 - need) * 0x11111111u, false};
+    const uint32_t top = 31u - __clz(max(need, 1u));
+    const uint32_t pre = 0x11111111u * ((0xFu << top) & 0xFu);
+    return need <= 8 ? Need{(8 - need) * 0x11111111u, true, pre} : Need{(16 - need) * 0x11111111u, false, pre};
   }
+  static __device__ __forceinline__ bool maybe(uint4 v, Need n) { return ((v.x | v.y | v.z | v.w) & n.pre) != 0; }
   static __device__ __forceinline__ uint32_t hits(uint32_t v, Need n) {
     const uint32_t t = (v & 0x77777777u) + n.bias;
     return (n.low ? (t | v) : (t & v)) & 0x88888888u;
@@ -631,7 +643,11 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       cnt128[i] = make_uint4(z, z, z, z);
       v = S::mask_pad(v, i);
       // one SWAR test per vector: the top bit of a field is set iff its counter >= need
+#if BLURRILY_SCAN_PREFILTER
+      if (S::maybe(v, nq) && S::any_hit(v, nq)) harvest(v, i);
+#else
       if (S::any_hit(v, nq)) harvest(v, i);
+#endif
     }
 #endif
   } else {
