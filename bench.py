@@ -282,6 +282,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     if rank == 0:
         # p50 single-needle latency through blurrily_storage_find (host buffers, sync per call)
         p50_us, host_rate = None, None
+        m.set_timing(False)          # (the HIP-event bracket of the timed steps is not part of a plain find)
         if latency_probes:
             raw = W.unpack(qp, qo[:latency_probes + 1])
             rows = (_native.TrigramMatch * limit)()
