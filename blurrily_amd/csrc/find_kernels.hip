@@ -436,6 +436,13 @@ __device__ __forceinline__ uint32_t hi_half_shl(uint32_t v) {
   return out;
 }
 
+// value << (amount & 31), the AND being the hardware's
+__device__ __forceinline__ uint32_t shl_low5(uint32_t value, uint32_t amount) {
+  uint32_t out;
+  asm("v_lshlrev_b32 %0, %1, %2" : "=v"(out) : "v"(amount), "v"(value));
+  return out;
+}
+
 // byte counters (ONE = 1) and 4-bit counters (ONE = 1: even window of the step, 16: odd window):
 // both ranks of a dword
 template <uint32_t ONE>
@@ -443,7 +450,10 @@ __device__ __forceinline__ void bump_pair_bytes(uint32_t* cnt32, uint32_t v) {
   static_assert(kWindowBits == 16, "the packed-dword arithmetic below is written for 16-bit in-window ranks");
   __hip_atomic_fetch_add(&cnt32[(v & 0xFFFFu) >> 2], ONE << ((v << 3) & 24u), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
-  __hip_atomic_fetch_add(&cnt32[v >> 18], ONE << (hi_half_shl<3>(v) & 24u), __ATOMIC_RELAXED,
+  // (the increment of the high half is shifted in asm as well: the hardware takes the low five bits of a
+  // shift amount, which is exactly (rank & 3) * 8 -- written in C++ the amount needs an AND that the
+  // compiler cannot drop behind the opaque SDWA result: 3.5 -> 3 VALU instructions per posting)
+  __hip_atomic_fetch_add(&cnt32[v >> 18], shl_low5(ONE, hi_half_shl<3>(v)), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
