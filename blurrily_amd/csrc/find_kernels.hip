@@ -1514,13 +1514,18 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
 // One task = (needle, window), run by a workgroup of 4 waves with 32 KiB of counters -- four
 // workgroups per CU: 4-bit counters for the whole window when a cold count cannot exceed 15 (nearly
 // always: the cold slices are few), else byte counters over the two halves of the window in turn.
-constexpr int      kWsNT    = 256;
+#ifndef BLURRILY_WS_THREADS
+#define BLURRILY_WS_THREADS 256        // (512 -- eight waves per task and SIMD, 64 VGPRs, 100 B of scratch -- measured:
+#endif                                 //  configs[2] 322 -> 346 ms per 300 k needles, configs[4] 82.3 -> 85.6 ms)
+constexpr int      kWsNT    = BLURRILY_WS_THREADS;
 constexpr uint32_t kWsNW    = kWsNT / 64;
+constexpr uint32_t kWsChunk = 256;             // most needles per queue pop (the task arrays in LDS)
+constexpr uint32_t kWsAhead = kWsNT >= 512 ? 2 : 4;   // units a wave loads before it counts the first of them
 constexpr uint32_t kWsCand  = 512;             // candidate list (rank | cold << 16): two per thread
 constexpr uint32_t kWsPool  = 256;             // candidate pool, >= 2 * kWsMaxKeep
 constexpr uint32_t kWsCntWords = kWindowSize / 8;   // 8192 words = 32 KiB: 65 536 nibbles or 32 768 bytes
 static_assert(kWsPool >= 2 * kWsMaxKeep && kWsPool <= uint32_t(kWsNT), "compact_pool's rank sort needs pool <= threads");
-static_assert(kWsCand == 2 * kWsNT, "the probe phase gives every thread two candidates");
+static_assert(kWsCand <= 2 * kWsNT, "the probe phase gives every thread at most two candidates");
 
 struct WsControl {
   Control  c;
@@ -1672,7 +1677,8 @@ __device__ __forceinline__ void ws_scan_fast(uint4* cnt128, uint32_t* cand, uint
                                              uint32_t need, uint32_t h, uint32_t wlen) {
   const WsLayout<WIDE> Y(need, h, wlen);
   const uint32_t tid = threadIdx.x;
-  constexpr uint32_t kRound = 4;                           // vectors of a thread in flight together
+  constexpr uint32_t kPerThread = kWsCntWords / 4 / kWsNT;
+  constexpr uint32_t kRound = kPerThread < 4 ? kPerThread : 4;   // vectors of a thread in flight together
 #pragma unroll 1
   for (uint32_t k0 = 0; k0 < kWsCntWords / 4 / kWsNT; k0 += kRound) {
     uint4 v[kRound];
@@ -1762,12 +1768,12 @@ __device__ __forceinline__ void ws_scan_robust(const FindArgs& A, uint4* cnt128,
 // phase clocks of wave 0 (stats mode only): FindArgs::stats[kStatWsClocks + phase]
 #define WS_CLOCK(i) do { if (STATS(A) && wid == 0) { const unsigned long long t_ = clock64(); ws_clk[i] += t_ - ws_last; ws_last = t_; } } while (0)
 
-__global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, const uint32_t w, const uint32_t n,
+__global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArgs A, const uint32_t w, const uint32_t n,
                                                           const uint32_t chunk_len, const uint32_t own_pass) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];       // + dump word
   __shared__ uint32_t s_cand[kWsCand];
   __shared__ unsigned long long s_pool[kWsPool];
-  __shared__ uint32_t s_task_q[kWsNT], s_task_meta[kWsNT], s_task_code[kWsNT];
+  __shared__ uint32_t s_task_q[kWsChunk], s_task_meta[kWsChunk], s_task_code[kWsChunk];
   __shared__ uint2 s_units[64];                 // what the owner wave publishes: the units to count (first entry, slice end)
   __shared__ uint32_t s_hot[64];                //   ... and the bitmaps of the slices it left out
   __shared__ WsControl s_ctl;
@@ -1920,10 +1926,10 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
           for (uint32_t h = 0; h < (wide ? 2u : 1u); ++h) {
             // ---- count: unit k belongs to wave k mod 4; four loads travel together ---------------------
             if (n_units <= 64) {
-              for (uint32_t k0 = wid; k0 < n_units; k0 += 4 * kWsNW) {
-                uint4 u[4];
+              for (uint32_t k0 = wid; k0 < n_units; k0 += kWsAhead * kWsNW) {
+                uint4 u[kWsAhead];
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
+                for (uint32_t i = 0; i < kWsAhead; ++i) {
                   const uint32_t k = k0 + i * kWsNW;
                   const uint2 d = s_units[min(k, 63u)];
                   const uint32_t c = __builtin_amdgcn_readfirstlane(d.x);
@@ -1932,7 +1938,7 @@ __global__ __launch_bounds__(kWsNT, 4) void wsweep_kernel(const FindArgs A, cons
                   if (STATS(A) && k < n_units) { st_ent += min(512u, e - c); ++st_units; }
                 }
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
+                for (uint32_t i = 0; i < kWsAhead; ++i) {
                   if (wide) ws_bump8<true>(s_cnt, u[i], h); else ws_bump8<false>(s_cnt, u[i], 0u);
                 }
               }
@@ -2207,7 +2213,7 @@ int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, boo
   if (n == 0) return 0;
   // needles per queue pop: whole 256-thread filters for big batches, smaller chunks when there are too
   // few needles to give every resident workgroup (four per CU) several chunks
-  uint32_t chunk_len = kWsNT;
+  uint32_t chunk_len = kWsChunk;
   while (chunk_len > 16 && (n + chunk_len - 1) / chunk_len < n_cus * 4u * 4u) chunk_len >>= 1;
   const uint32_t chunks = (n + chunk_len - 1) / chunk_len;
   const uint32_t grid = std::min(chunks, n_cus * 4u);
