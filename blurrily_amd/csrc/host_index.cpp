@@ -73,6 +73,11 @@ void RefSet::rehash(uint64_t want) {
   while (cap < want * 2) cap <<= 1;
   uint32_t* nk = static_cast<uint32_t*>(std::malloc(cap * sizeof(uint32_t)));
   uint8_t*  nt = static_cast<uint8_t*>(std::calloc(cap, 1));
+  if (!nk || !nt) {                                               // out of memory: keep the table as it is (it is
+    std::free(nk); std::free(nt);                                 // grown long before it is full, so adds still fit)
+    if (cap_) return;
+    std::fprintf(stderr, "blurrily_hip: out of memory\n"); std::abort();
+  }
   uint64_t live = 0;
   for (uint64_t i = 0; i < cap_; ++i) {
     if (tag_[i] != 1) continue;
@@ -155,21 +160,30 @@ int HostIndex::put(const char* needle, size_t len, uint32_t ref, uint32_t weight
   uint16_t  small[256];
   uint16_t* codes = (len + 1 <= 256) ? small
                                      : static_cast<uint16_t*>(std::malloc((len + 1) * sizeof(uint16_t)));
+  if (!codes) { errno = ENOMEM; return -1; }
   const int n = tokenise(needle, len, codes);                     // storage.c:412
 
-  for (int k = 0; k < n; ++k) {                                   // storage.c:415-465
+  // Room first, entries after: an allocation that fails leaves the map as it was (the reference's
+  // smalloc asserts instead, storage.c:93-98).  A bucket grows exactly when the reference's would --
+  // when it is full and about to take an entry -- so files stay byte-identical.
+  for (int k = 0; k < n; ++k) {                                   // storage.c:424-458
     Bucket& bk = b_[codes[k]];
     if (bk.slots == 0) {                                          // :424-429
-      bk.slots = kFirstSlots;
-      bk.e = alloc_slots(bk.slots);
+      Entry* ne = alloc_slots(kFirstSlots);
+      if (!ne) { if (codes != small) std::free(codes); errno = ENOMEM; return -1; }
+      bk.e = ne; bk.slots = kFirstSlots;
     } else if (bk.used == bk.slots) {                             // :430-458
       uint32_t grown = uint32_t(uint64_t(bk.slots) * 4 / 3);
       if (grown <= bk.slots) grown = bk.slots + 1;                // only for hand-made files with < 3 slots
       Entry* ne = alloc_slots(grown);
+      if (!ne) { if (codes != small) std::free(codes); errno = ENOMEM; return -1; }
       std::memcpy(ne, bk.e, size_t(bk.slots) * sizeof(Entry));
       std::free(bk.e);
       bk.e = ne; bk.slots = grown;
     }
+  }
+  for (int k = 0; k < n; ++k) {                                   // storage.c:462-465
+    Bucket& bk = b_[codes[k]];
     bk.e[bk.used].ref = ref;                                      // :462-464
     bk.e[bk.used].weight = weight;
     bk.used += 1;
@@ -269,6 +283,10 @@ long HostIndex::put_many(const char* packed, const uint64_t* offsets, const uint
         }
         if (slots != bk.slots) {
           Entry* ne = alloc_slots(slots);
+          if (!ne) {                                              // mid-way through a bulk import on all cores:
+            std::fprintf(stderr, "blurrily_hip: out of memory growing a bucket\n");   // nothing sane to return to
+            std::abort();
+          }
           if (bk.slots) std::memcpy(ne, bk.e, size_t(bk.slots) * sizeof(Entry));
           std::free(bk.e);
           bk.e = ne; bk.slots = slots;
@@ -473,6 +491,7 @@ HostIndex* HostIndex::load(const char* path) {
     Bucket& bk = ix->b_[t];
     bk.slots = slots; bk.used = used; bk.dirty = d[24];
     bk.e = static_cast<Entry*>(std::malloc(std::max<size_t>(block, 1)));
+    if (!bk.e) { bk.slots = bk.used = 0; delete ix; ::munmap(mem, size); errno = ENOMEM; return nullptr; }
     std::memcpy(bk.e, base + off, block);
   }
   ::munmap(mem, size);

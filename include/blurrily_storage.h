@@ -69,7 +69,9 @@ void blurrily_storage_mark(trigram_map haystack);
 int blurrily_storage_save(trigram_map haystack, const char* path);
 
 /* storage.h:70 / storage.c:398-473.  Returns the number of trigrams added,
- * 0 if `reference` is already present.  weight == 0 -> strlen(needle). */
+ * 0 if `reference` is already present.  weight == 0 -> strlen(needle).
+ * Out of memory: -1 with errno ENOMEM and the map unchanged (the reference
+ * asserts in smalloc, storage.c:93-98). */
 int blurrily_storage_put(trigram_map haystack, const char* needle,
                          uint32_t reference, uint32_t weight);
 
