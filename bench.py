@@ -189,8 +189,9 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     block = ResultBlock(n_q, limit, device=dev)
     d_nb = torch.empty((n_q,), dtype=torch.int32, device=dev)
     gathered = None
+    host_gather = world > 1 and dist.get_backend() != "nccl"      # (smoke-test mode, see main)
     if world > 1 and rank == 0:
-        gathered = torch.empty((world, block.buf.numel()), dtype=torch.int32, device=dev)
+        gathered = torch.empty((world, block.buf.numel()), dtype=torch.int32, device="cpu" if host_gather else dev)
     lib = _native.lib()
     m.set_timing(True)
     stream = torch.cuda.current_stream().cuda_stream
@@ -208,7 +209,10 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
         kernel_ms.append(m.device_info()["last_find_kernel_ms"])     # (timing mode: the call has synchronised)
         if world > 1:
             t = time.perf_counter()
-            gather_blocks(dist, block, gathered, rank)
+            if host_gather:
+                gather_blocks(dist, ResultBlock(n_q, limit, buf=block.buf.cpu()), gathered, rank)
+            else:
+                gather_blocks(dist, block, gathered, rank)
             torch.cuda.synchronize()
             gather_ms.append(1e3 * (time.perf_counter() - t))
 
@@ -227,8 +231,9 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    coll_dev = "cpu" if host_gather else dev
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -268,7 +273,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     phys_gbs = phys_bytes / (k_ms * 1e-3) / 1e9
 
     totals = torch.tensor([float(sum_nb), k_ms, float(np.mean(gather_ms)) if gather_ms else 0.0],
-                          dtype=torch.float64, device=dev)
+                          dtype=torch.float64, device=coll_dev)
     per_rank = None
     if world > 1:
         allr = [torch.zeros_like(totals) for _ in range(world)]
@@ -375,6 +380,11 @@ def main():
             raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: blurrily_amd has no CPU fallback")
+    # (BLURRILY_DIST_BACKEND=gloo: plumbing smoke test of the N > 1 path on a box with fewer GPUs than ranks --
+    # ranks share devices and the result blocks are gathered through host memory; never a measurement)
+    backend = os.environ.get("BLURRILY_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -383,7 +393,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # every rank builds the same (seeded) haystack: share the host's cores between the ranks
         os.environ.setdefault("BLURRILY_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     main_name = args.workload or "geonames"
     budget = 0.0 if args.no_cpu_baseline else args.cpu_budget

@@ -104,3 +104,33 @@ def test_the_benched_call_on_the_benched_batch(name, n_sample):
     assert np.array_equal(h_counts.astype(np.int64), counts[lo:hi])
     live_s = np.arange(limit)[None, :] < counts[lo:hi, None]
     assert np.array_equal(np.where(live_s[:, :, None], h_rows, 0), np.where(live_s[:, :, None], rows[lo:hi], 0))
+
+
+def test_bench_two_ranks_plumbing(tmp_path):
+    """bench.py's N > 1 path end to end -- per-rank shards, ONE gather of the result blocks, max-over-ranks
+    timing, the JSON line's per-rank fields -- as two ranks sharing this box's GPU, the blocks gathered
+    through host memory over gloo (BLURRILY_DIST_BACKEND; RCCL needs a GPU per rank).  A plumbing test,
+    not a measurement."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BLURRILY_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"]
+    res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["needles_per_gpu"] == 50000 and d["config"]["index_replicated"] is True
+    assert abs(d["value"] - 2 * 50000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6      # whole-job needles/s
+    assert len(d["per_rank"]["kernel_ms"]) == 2 and len(d["per_rank"]["gather_ms"]) == 2
+    assert d["gather_bytes_per_rank"] == 50000 * (10 * 12 + 4) and d["gather_ms"] > 0
+    assert "cpu_baseline" not in d and "extra_configs" not in d
