@@ -95,6 +95,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_SCAN_PREFILTER
 #define BLURRILY_SCAN_PREFILTER 1      // the scan tests a vector with one AND before the exact SWAR test
 #endif
+#ifndef BLURRILY_COOP_PUBLISH
+#define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
+#endif
 #ifndef BLURRILY_HEAD_UNITS
 #define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
 #endif
@@ -1010,6 +1013,8 @@ constexpr uint32_t kRingUnits = 256;                            // descriptors p
 struct UnitRing {
   uint2    desc[2][kRingUnits];                                 // .x first entry of the unit, .y end of its slice
   uint32_t n_units[2];                                          // kRingOverflow: too many units, walk the table
+  uint32_t step[2];                                             // which step the slot's units belong to (past the end: none)
+  uint32_t visit[2];                                            // the visit index chosen most recently, by turns
 };
 constexpr uint32_t kRingOverflow = 0xFFFFFFFFu;
 
@@ -1131,6 +1136,77 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
   uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0;    // request counters (FindArgs::stats), wave-uniform
+#if BLURRILY_COOP_PUBLISH
+  // Which step comes next is decided by ONE wave per step -- the one that then fetches that step's table --
+  // and travels through LDS with the units: `step[slot]` beside `n_units[slot]`, the visit index chosen last in
+  // `visit[]`.  The other fifteen waves read two words per step instead of each running the window-bound
+  // loop, the 64-bit threshold arithmetic and the step bookkeeping themselves (the kernel keeps its VALU
+  // pipes ~85 % busy, half of it such bookkeeping repeated in every wave, profiles/r02_old_pmc.txt).
+  uint32_t my_i = 0;                                            // visit index of the table this wave holds
+  if (wid == BLURRILY_PRODUCER(0u)) {
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
+    BLURRILY_PRODUCE(0u, ta, tb, ta1, tb1);
+    if (lane == 0) ring->step[0] = BLURRILY_STEP_AT(0u);
+  }
+  if (wid == BLURRILY_PRODUCER(1u)) {
+    BLURRILY_NEXT_VISIT(1u, my_i);
+    if (lane == 0) ring->visit[1] = my_i;
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);
+  }
+  __syncthreads();
+
+  for (uint32_t e = 0;; ++e) {
+    const uint32_t s = e & 1;
+    const uint32_t p = __builtin_amdgcn_readfirstlane(ring->step[s]);
+    if (p >= v1) break;                                         // no step left
+    const uint32_t n_units = __builtin_amdgcn_readfirstlane(ring->n_units[s]);
+    const uint32_t wbase = p * kWPS * kWindowRanks;
+    const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
+    ++st_steps;
+    PHASE_MARK(0);                                              // loop overhead
+    // ---- count step p --------------------------------------------------------------------
+    if (n_units == kRingOverflow) {
+      BLURRILY_COUNT_WALK(p);
+    } else {
+      BLURRILY_COUNT_UNITS(s, n_units);
+    }
+    PHASE_MARK(2);                                              // units counted
+    // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
+    if (wid == BLURRILY_PRODUCER(e + 1)) {
+      if (my_i < n_visit) {
+        BLURRILY_PRODUCE(s ^ 1u, ta, tb, ta1, tb1);
+        if (lane == 0) ring->step[s ^ 1u] = BLURRILY_STEP_AT(my_i);
+      } else if (lane == 0) {
+        ring->n_units[s ^ 1u] = 0; ring->step[s ^ 1u] = v1;
+      }
+    }
+    PHASE_MARK(7);                                              // (producer turn) next step's units published
+    // the wave after it chooses the step after the next (the threshold only changes behind select's
+    // barriers) and fetches its table, which travels during the barrier and the scan
+    if (wid == BLURRILY_PRODUCER(e + 2)) {
+      const uint32_t chosen = __builtin_amdgcn_readfirstlane(ring->visit[(e + 1) & 1]);
+      BLURRILY_NEXT_VISIT(chosen + 1, my_i);
+      if (lane == 0) ring->visit[e & 1] = my_i;
+      BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);
+    }
+    __syncthreads();                                            // counts and next descriptors visible
+    PHASE_MARK(3);                                              // barrier after count
+    PHASE_MARK(4);
+    if (n_units) {
+      for (;;) {
+        scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
+        PHASE_MARK(5);                                          // scan
+        __syncthreads();                                        // counters are zero again
+        PHASE_MARK(6);                                          // barrier after scan
+        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
+        ++st_redo;
+        if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
+        else BLURRILY_COUNT_UNITS(s, n_units);
+        __syncthreads();
+      }
+    }
+  }
+#else
   uint32_t i_cur = 0, i_next, i_next2;
   // prologue: one wave publishes the first step, everyone agrees on the second
   if (wid == BLURRILY_PRODUCER(0u)) {
@@ -1193,6 +1269,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     i_cur = i_next;
     i_next = i_next2;
   }
+#endif
   PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
     atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
