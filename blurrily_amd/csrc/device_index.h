@@ -9,7 +9,7 @@
 //     is exactly "matches descending, rank ascending": the kernel never needs
 //     a weight while it counts and selects.  ref_of_rank / weight_of_rank are
 //     the side tables read when result rows are written.
-//   * the rank space is cut into windows of kWindowRanks = 65 535 ranks; the
+//   * the rank space is cut into windows of kWindowRanks = 65 520 ranks; the
 //     postings are stored window-major: for window w, for trigram code t, the
 //     16-bit in-window ranks of the references whose string contains t, sorted,
 //     each 512-entry unit (one wave-load) stored transposed so that one LDS
@@ -46,7 +46,10 @@ namespace blurrily {
 #endif
 constexpr uint32_t kWindowBits  = BLURRILY_WINDOW_BITS;
 constexpr uint32_t kWindowSize  = 1u << kWindowBits;    // counter slots per window (LDS)
-constexpr uint32_t kWindowRanks = kWindowSize - 1;      // ranks per window; slot 0xFFFF = padding sentinel
+// Ranks per window: the last 16 counter slots stay free of references -- slot 0xFFFF is the padding
+// sentinel's, and with the other 15 unused as well the needle-major scan never has to read (and mask)
+// the 16-byte vector that holds it: three VALU instructions per scanned vector less.
+constexpr uint32_t kWindowRanks = kWindowSize - 16;
 constexpr uint16_t kPadRank     = uint16_t(kWindowSize - 1);
 constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byte over-reads)
 // A (window, code) slice with at least this many postings also exists as a BITMAP of the window

@@ -98,6 +98,10 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_COOP_PUBLISH
 #define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
 #endif
+#ifndef BLURRILY_CLEAR_WRITE2
+#define BLURRILY_CLEAR_WRITE2 0        // 1: the scan clears a vector with ds_write2_b64 from one 64-bit zero -- 6 VALU per
+                                       // scanned vector instead of 10, yet 2.3 % SLOWER (356.5 vs 348.3 ms, same box)
+#endif
 #ifndef BLURRILY_HEAD_UNITS
 #define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
 #endif
@@ -345,6 +349,7 @@ template <> struct Packing<Nib> {
 
 // What the scan needs to know about a packing: which vectors to read, which counters reached
 // `need` (one bit per counter, at the top bit of its field), where the padding slots are.
+static_assert(kWindowRanks + 16 <= kWindowSize, "the scan relies on the last 16 counter slots holding no reference");
 template <typename CT> struct ScanTraits {
   using P = Packing<CT>;
   static constexpr uint32_t kVecs = kWindowSize * sizeof(CT) / 16;
@@ -362,10 +367,9 @@ template <typename CT> struct ScanTraits {
     return ((v.x + n.bias) | (v.y + n.bias) | (v.z + n.bias) | (v.w + n.bias)) & P::kHi;
   }
   static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) { return (wlen * uint32_t(sizeof(CT)) + 15) / 16; }
-  static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t i) {
-    if (i == kVecs - 1) v.w &= ~(P::kMask << (32 - P::kBits));    // slot 0xFFFF counts padding
-    return v;
-  }
+  // The vector holding slot 0xFFFF (padding) holds no reference (kWindowRanks leaves the last 16 slots
+  // free), so nvec() never reaches it: nothing to mask; clear_unreached_pad clears it every step.
+  static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t) { return v; }
   static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) { return wbase + idx; }
   // a short window does not reach the vector holding the padding slot: clear it here
   static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
@@ -394,10 +398,7 @@ template <> struct ScanTraits<Nib> {
   }
   // bytes in use: in-window ranks [0, min(wlen, one window)) -- the odd window is never longer than the even one
   static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) { return (min(wlen, kWindowRanks) + 15) / 16; }
-  static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t i) {
-    if (i == kVecs - 1) v.w &= 0x00FFFFFFu;                         // slot 0xFFFF of both windows counts padding
-    return v;
-  }
+  static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t) { return v; }   // (as above: never reached)
   // counter index = 8 * word + nibble; nibble = 2 * (byte in word) + (window parity)
   static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
     return wbase + (idx & 1u) * kWindowRanks + (idx >> 1);
@@ -595,6 +596,13 @@ __device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint3
       (const __attribute__((address_space(3))) void*)p));
 }
 
+// 16 bytes of LDS zeroed with one ds_write2_b64 whose two data operands are the same zero pair
+[[maybe_unused]] __device__ __forceinline__ void lds_zero16(void* p16) {
+  const uint32_t a = lds_offset_of(p16);
+  unsigned long long z = 0;
+  asm volatile("ds_write2_b64 %0, %1, %1 offset1:1" :: "v"(a), "v"(z) : "memory");
+}
+
 // ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
@@ -649,11 +657,18 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
 #else
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint4 v = cnt128[i];
+#if BLURRILY_CLEAR_WRITE2
+      // 16 bytes of zeros from ONE 64-bit zero (ds_write2_b64 takes the same register pair twice): a
+      // zero quad would be re-materialised every iteration (four v_mov) or, hoisted, spill under the
+      // 64-VGPR budget
+      lds_zero16(&cnt128[i]);
+#else
       // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held
       // in four VGPRs for the whole sweep and spilled to scratch under the 64-VGPR budget.
       uint32_t z = 0;
       asm volatile("" : "+v"(z));
       cnt128[i] = make_uint4(z, z, z, z);
+#endif
       v = S::mask_pad(v, i);
       // one SWAR test per vector: the top bit of a field is set iff its counter >= need
 #if BLURRILY_SCAN_PREFILTER
