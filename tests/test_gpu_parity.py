@@ -351,7 +351,7 @@ def test_very_long_needles_and_haystack_strings():
 
 @pytest.mark.parametrize("n", [65519, 65520, 65521, 65535, 65536, 131039, 131040, 131041])
 def test_window_boundaries_and_cross_window_ties(n):
-    """Haystack sizes around the 65 535-rank window: every string ties with every other on
+    """Haystack sizes around the 65 520-rank window (and the 65 535 it used to be): every string ties with every other on
     (matches, weight), so the order is purely reference-ascending across window boundaries,
     including limits that cross a window and the multi-pass path."""
     m, o = RawMap(), Oracle()
