@@ -148,3 +148,27 @@ def test_small_batches_and_small_haystacks_keep_the_needle_major_path(ws_env):
     m, o = _pair(hay, off)
     q, qo = W.queries(hay, off, 500, 52)                       # default bounds: 500 needles is a small batch
     _check_all(m, o, q, qo, 10, took_ws=False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_window_major_configurations(ws_env, seed):
+    """Seeded random configurations of the window-major sweep -- haystack kind and size (5 to 11 windows),
+    limit, cmin, reference numbering (dense / sparse), a sprinkle of deletes -- every row against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["geonames", "skewed", "words"][seed % 3]
+    n = int(rng.integers(300_000, 700_000))
+    limit = int(rng.choice([1, 2, 7, 10, 33, 100, 128]))
+    ws_env(WS_MIN_WINDOWS=2, WS_MIN_NEEDLES=500, WS_CMIN=int(rng.integers(1, 5)))
+    hay, off = {"geonames": lambda: W.geonames(n, 50000, 60 + seed), "skewed": lambda: W.skewed(n, 60 + seed),
+                "words": lambda: W.words(n, 60 + seed)}[kind]()
+    refs = np.arange(1, n + 1, dtype=np.uint32)
+    if seed % 2:
+        refs = (np.sort(rng.choice(2**31 - 2, size=n, replace=False)) + 1).astype(np.uint32)   # sparse references
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(hay, off, refs)
+    o.put_many(hay, off, refs)
+    q, qo = W.queries(hay, off, 1500, 70 + seed)
+    _check_all(m, o, q, qo, limit)
+    for ref in rng.choice(refs, size=200, replace=False):       # tombstones on the base image
+        assert m.delete(int(ref)) == o.delete(int(ref))
+    _check_all(m, o, q, qo, limit)
