@@ -44,10 +44,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (imported before the HIP library so both share one HIP runtime)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# LDS atomics: a no-return ds_add_u32 moves an address and a data VGPR like ds_write_b32, whose rate
-# MI355X_MICROARCH.md (section LDS) gives as 4 cycles per wave-instruction = 16 lanes per clock per
-# CU, bank-conflict free; 256 CUs at 2.4 GHz.
-LDS_ATOMIC_PEAK_LANES = 16 * 256 * 2.4e9
+# LDS atomics: no-return ds_add_u32 lanes per second, whole chip, MEASURED (tools/micro/lds_atomic_rate.hip,
+# profiles/r02_lds_atomic_rate.txt: conflict-free addresses, find_kernel's residency; 6.97e12 with random
+# addresses).  MI355X_MICROARCH.md's ds_write_b32 figure -- 16 lanes per clock per CU -- gives 9.83e12 at 2.4 GHz;
+# under this load the chip clocks 1.6 GHz and retires 22.7 lanes per clock per CU.
+LDS_ATOMIC_PEAK_LANES = 9.34e12
 
 
 def log(msg):
