@@ -2344,7 +2344,9 @@ int find_threads() {
 uint32_t find_wgs_per_cu() {
   const uint32_t by_lds = uint32_t((160 * 1024) / find_lds_bytes(1, 1024));
   const uint32_t by_waves = 32u / uint32_t(find_threads() / 64);
-  return std::max(1u, std::min(by_lds, by_waves));
+  uint32_t n = std::max(1u, std::min(by_lds, by_waves));
+  if (const char* e = std::getenv("BLURRILY_FIND_WGS_PER_CU")) n = std::max(1, std::min<int>(int(n), std::atoi(e)));   // experiments
+  return n;
 }
 
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
