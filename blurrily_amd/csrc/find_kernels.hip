@@ -337,11 +337,12 @@ template <> struct Packing<uint16_t> {
 
 // 4-bit counters for needles with at most 15 distinct trigrams (two needles in three at
 // Geonames scale): the same 64 KiB of LDS then hold TWO windows, so a sweep takes half the steps.
-// In-window rank r keeps its byte-counter address (word r >> 2, byte r & 3); the even window
+// In-window rank r keeps its byte-counter address (word r >> 2, byte 3 - (r & 3)); the even window
 // of the step counts in the low nibble of that byte, the odd one in the high nibble -- so a
 // posting costs the same instructions as with byte counters, the increment being 1 or 16 shifted
-// by the byte position.  Both nibbles of the padding slot 0xFFFF sit in the top byte of the
-// last word: their overflow leaves the word.
+// by the byte position.  Both nibbles of the padding slot 0xFFFF sit in the lowest byte of the
+// last word, whose other three bytes belong to no reference (kWindowRanks): their overflow harms nobody,
+// and the word is cleared every step.
 struct Nib {};
 template <> struct Packing<Nib> {
   static constexpr uint32_t kPerWord = 8, kBits = 4, kMask = 0xFu;
@@ -370,7 +371,10 @@ template <typename CT> struct ScanTraits {
   // The vector holding slot 0xFFFF (padding) holds no reference (kWindowRanks leaves the last 16 slots
   // free), so nvec() never reaches it: nothing to mask; clear_unreached_pad clears it every step.
   static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t) { return v; }
-  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) { return wbase + idx; }
+  // counter index = kPerWord * word + field; byte counters sit in descending rank order inside their word
+  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
+    return wbase + (sizeof(CT) == 1 ? idx ^ 3u : idx);
+  }
   // a short window does not reach the vector holding the padding slot: clear it here
   static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
     if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
@@ -399,9 +403,9 @@ template <> struct ScanTraits<Nib> {
   // bytes in use: in-window ranks [0, min(wlen, one window)) -- the odd window is never longer than the even one
   static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) { return (min(wlen, kWindowRanks) + 15) / 16; }
   static __device__ __forceinline__ uint4 mask_pad(uint4 v, uint32_t) { return v; }   // (as above: never reached)
-  // counter index = 8 * word + nibble; nibble = 2 * (byte in word) + (window parity)
+  // counter index = 8 * word + nibble; nibble = 2 * (byte in word) + (window parity); byte = 3 - (rank & 3)
   static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
-    return wbase + (idx & 1u) * kWindowRanks + (idx >> 1);
+    return wbase + (idx & 1u) * kWindowRanks + ((idx >> 1) ^ 3u);
   }
   static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
     if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
@@ -440,24 +444,35 @@ __device__ __forceinline__ uint32_t hi_half_shl(uint32_t v) {
   return out;
 }
 
-// value << (amount & 31), the AND being the hardware's
-__device__ __forceinline__ uint32_t shl_low5(uint32_t value, uint32_t amount) {
+// value >> (amount & 31), the AND being the hardware's
+__device__ __forceinline__ uint32_t shr_low5(uint32_t value, uint32_t amount) {
   uint32_t out;
-  asm("v_lshlrev_b32 %0, %1, %2" : "=v"(out) : "v"(amount), "v"(value));
+  asm("v_lshrrev_b32 %0, %1, %2" : "=v"(out) : "v"(amount), "v"(value));
+  return out;
+}
+
+// top >> (8 * (sel & 3)): v_alignbyte_b32 shifts {0, top} right by the bytes its third operand's low TWO bits
+// name (gfx950: tools/micro/alignbyte_probe.hip) -- a byte counter's increment straight from the posting
+__device__ __forceinline__ uint32_t shr_bytes_low2(uint32_t top, uint32_t sel) {
+  uint32_t out;
+  asm("v_alignbyte_b32 %0, 0, %1, %2" : "=v"(out) : "s"(top), "v"(sel));
   return out;
 }
 
 // byte counters (ONE = 1) and 4-bit counters (ONE = 1: even window of the step, 16: odd window):
-// both ranks of a dword
+// both ranks of a dword.  In-window rank r counts in word r >> 2, byte 3 - (r & 3) -- the bytes of a word in
+// DESCENDING rank order, so that the increment is the constant ONE << 24 moved down by (r & 3) bytes.
 template <uint32_t ONE>
 __device__ __forceinline__ void bump_pair_bytes(uint32_t* cnt32, uint32_t v) {
   static_assert(kWindowBits == 16, "the packed-dword arithmetic below is written for 16-bit in-window ranks");
-  __hip_atomic_fetch_add(&cnt32[(v & 0xFFFFu) >> 2], ONE << ((v << 3) & 24u), __ATOMIC_RELAXED,
+  constexpr uint32_t kTop = ONE << 24;
+  // low half: address and increment are one instruction each (the shift by bytes reads bits 1:0 of v itself)
+  __hip_atomic_fetch_add(&cnt32[(v & 0xFFFFu) >> 2], shr_bytes_low2(kTop, v), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
-  // (the increment of the high half is shifted in asm as well: the hardware takes the low five bits of a
-  // shift amount, which is exactly (rank & 3) * 8 -- written in C++ the amount needs an AND that the
-  // compiler cannot drop behind the opaque SDWA result: 3.5 -> 3 VALU instructions per posting)
-  __hip_atomic_fetch_add(&cnt32[v >> 18], shl_low5(ONE, hi_half_shl<3>(v)), __ATOMIC_RELAXED,
+  // high half: (rank << 3) by SDWA operand select, then the shift whose amount the hardware masks to five
+  // bits, which is exactly (rank & 3) * 8 -- written in C++ the amount needs an AND that the compiler cannot
+  // drop behind the opaque SDWA result.  3 + 2 VALU instructions per pair of postings.
+  __hip_atomic_fetch_add(&cnt32[v >> 18], shr_low5(kTop, hi_half_shl<3>(v)), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
