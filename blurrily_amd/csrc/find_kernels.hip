@@ -96,15 +96,6 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #define BLURRILY_SCAN_PREFILTER 1      // the scan tests a vector with one AND before the exact SWAR test
 #endif
 #ifndef BLURRILY_COOP_PUBLISH
-#ifndef BLURRILY_SKIP_EXPERIMENT
-#define BLURRILY_SKIP_EXPERIMENT 0     // timing experiment only, see sweep_coop
-#endif
-#ifndef BLURRILY_SKIP_EXPERIMENT_MIN
-#define BLURRILY_SKIP_EXPERIMENT_MIN 2048
-#endif
-#ifndef BLURRILY_SKIP_EXPERIMENT_CMIN
-#define BLURRILY_SKIP_EXPERIMENT_CMIN 3
-#endif
 #define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
 #endif
 #ifndef BLURRILY_CLEAR_WRITE2
@@ -1213,27 +1204,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
     if (wid == BLURRILY_PRODUCER(e + 1)) {
       if (my_i < n_visit) {
-#if BLURRILY_SKIP_EXPERIMENT
-        {  // TIMING ONLY (results wrong): the largest slice of each window left out once a threshold exists
-          const uint32_t need_ = matches_needed(ctl->thr, tc, BLURRILY_STEP_AT(my_i) * kWPS * kWindowRanks);
-          if (need_ >= BLURRILY_SKIP_EXPERIMENT_CMIN + 1) {
-            uint32_t sz0 = tb - ta, sz1 = tb1 - ta1, m0 = sz0, m1 = sz1;
-            _Pragma("unroll") for (uint32_t d_ = 32; d_; d_ >>= 1) {
-              m0 = max(m0, uint32_t(__shfl_xor(m0, int(d_)))); m1 = max(m1, uint32_t(__shfl_xor(m1, int(d_))));
-            }
-            if (m0 >= BLURRILY_SKIP_EXPERIMENT_MIN && sz0 == m0) tb = ta;
-            if (kNib && m1 >= BLURRILY_SKIP_EXPERIMENT_MIN && sz1 == m1) tb1 = ta1;
-            if (BLURRILY_SKIP_EXPERIMENT >= 2 && need_ >= BLURRILY_SKIP_EXPERIMENT_CMIN + 2) {
-              sz0 = tb - ta; sz1 = tb1 - ta1; m0 = sz0; m1 = sz1;
-              _Pragma("unroll") for (uint32_t d_ = 32; d_; d_ >>= 1) {
-                m0 = max(m0, uint32_t(__shfl_xor(m0, int(d_)))); m1 = max(m1, uint32_t(__shfl_xor(m1, int(d_))));
-              }
-              if (m0 >= BLURRILY_SKIP_EXPERIMENT_MIN && sz0 == m0) tb = ta;
-              if (kNib && m1 >= BLURRILY_SKIP_EXPERIMENT_MIN && sz1 == m1) tb1 = ta1;
-            }
-          }
-        }
-#endif
         BLURRILY_PRODUCE(s ^ 1u, ta, tb, ta1, tb1);
         if (lane == 0) ring->step[s ^ 1u] = BLURRILY_STEP_AT(my_i);
       } else if (lane == 0) {
