@@ -96,6 +96,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #define BLURRILY_SCAN_PREFILTER 1      // the scan tests a vector with one AND before the exact SWAR test
 #endif
 #ifndef BLURRILY_COOP_PUBLISH
+#ifndef BLURRILY_LANE_PREDICATE
+#define BLURRILY_LANE_PREDICATE 1       // sweep_coop: a unit's loaded lanes as a lane predicate, not as sentinels in idle lanes
+#endif
 #define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
 #endif
 #ifndef BLURRILY_CLEAR_WRITE2
@@ -508,6 +511,26 @@ __device__ __forceinline__ void bump8_nib(uint32_t* cnt32, const uint4 v) {
 // (Reading the short last unit of a slice with four or two ranks per lane -- fewer, fuller
 // atomic instructions -- was measured: 17% slower.  The LDS atomics cost by lane and by bank
 // conflict, not by instruction, and the narrow reads undo the bank-aware dealing.)
+// the same for a lane KNOWN to hold a loaded group (sweep_coop carries the load's lane predicate instead of
+// filling idle lanes with sentinels): no liveness test
+template <typename CT>
+__device__ __forceinline__ void bump_unit_loaded(uint32_t* cnt32, const uint4 v, uint32_t half) {
+  static_assert(sizeof(CT) == 1 || std::is_same<CT, Nib>::value, "byte and 4-bit counters only");
+  if constexpr (std::is_same<CT, Nib>::value) {
+    if (half) {
+      bump_pair_bytes<16>(cnt32, v.x); bump_pair_bytes<16>(cnt32, v.y);
+      bump_pair_bytes<16>(cnt32, v.z); bump_pair_bytes<16>(cnt32, v.w);
+    } else {
+      bump_pair_bytes<1>(cnt32, v.x); bump_pair_bytes<1>(cnt32, v.y);
+      bump_pair_bytes<1>(cnt32, v.z); bump_pair_bytes<1>(cnt32, v.w);
+    }
+  } else {
+    (void)half;
+    bump_pair_bytes<1>(cnt32, v.x); bump_pair_bytes<1>(cnt32, v.y);
+    bump_pair_bytes<1>(cnt32, v.z); bump_pair_bytes<1>(cnt32, v.w);
+  }
+}
+
 template <typename CT>
 __device__ __forceinline__ void bump_unit(uint32_t* cnt32, const uint4 v, uint32_t half) {
   if constexpr (std::is_same<CT, Nib>::value) {
@@ -1058,7 +1081,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   constexpr bool kNib = std::is_same<CT, Nib>::value;
   constexpr uint32_t kWPS = kNib ? 2 : 1;
   constexpr uint32_t kNW = NT / 64;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tc = nd.T;                                     // <= 64
   const bool own = lane < tc;
   const uint32_t code = own ? codes[lane] : 0u;
@@ -1132,6 +1155,29 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   } while (0)
   // the units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
   // atomics run while the next unit's load is in flight
+#if BLURRILY_LANE_PREDICATE
+  /* which lanes loaded a group travels as a lane predicate (an SGPR pair) beside the unit in flight: no         \
+     sentinels to fill idle lanes with, no liveness test before the atomics */                                  \
+#define BLURRILY_COUNT_UNITS(s_, n_)                                             \
+  do {                                                                           \
+    uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
+    uint32_t pend_h_ = 0;                                                        \
+    bool pend_live_ = false;                                                     \
+    for (uint32_t k_ = wid; k_ < (n_); k_ += kNW) {                              \
+      const uint2 d_ = ring->desc[s_][k_];                                       \
+      const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                  \
+      const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                  \
+      const uint32_t c_ = (x_ & ~7u) + lane * 8;                                 \
+      const bool live_ = c_ < y_;                                                \
+      uint4 v_ = pend_;                                                          \
+      if (live_) v_ = *reinterpret_cast<const uint4*>(A.ent + c_);               \
+      if (STATS(A)) st_ent += min(512u, y_ - (x_ & ~7u));                        \
+      if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);               \
+      pend_ = v_; pend_h_ = x_ & 1u; pend_live_ = live_;                         \
+    }                                                                            \
+    if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);                 \
+  } while (0)
+#else
 #define BLURRILY_COUNT_UNITS(s_, n_)                                             \
   do {                                                                           \
     uint4 pend_ = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);            \
@@ -1144,6 +1190,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     }                                                                            \
     bump_unit<CT>(cnt32, pend_, pend_h_);                                        \
   } while (0)
+#endif
   // more units than the ring holds: every wave walks the table of step p_ itself
 #define BLURRILY_COUNT_WALK(p_)                                                  \
   do {                                                                           \
