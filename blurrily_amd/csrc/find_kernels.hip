@@ -99,6 +99,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_LANE_PREDICATE
 #define BLURRILY_LANE_PREDICATE 1       // sweep_coop: a unit's loaded lanes as a lane predicate, not as sentinels in idle lanes
 #endif
+#ifndef BLURRILY_WMT_IN_LDS
+#define BLURRILY_WMT_IN_LDS 1          // the per-window bound as bytes in LDS (find_kernel), read by the step-choosing wave
+#endif
 #define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
 #endif
 #ifndef BLURRILY_CLEAR_WRITE2
@@ -1073,8 +1076,8 @@ constexpr uint32_t kRingOverflow = 0xFFFFFFFFu;
 
 template <typename CT, int NT>
 __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
-                           unsigned long long* pool, Control* ctl, UnitRing* ring, const uint32_t w0,
-                           const uint32_t w1, const uint32_t ws) {
+                           unsigned long long* pool, Control* ctl, UnitRing* ring, const uint8_t* wmt,
+                           const uint32_t w0, const uint32_t w1, const uint32_t ws) {
   // A step covers kWPS windows: one with byte counters, two with 4-bit counters (CT = Nib).  Lane
   // t of the table holds trigram t's slice of the step's window -- of both windows with 4-bit
   // counters (second slot) -- and a unit's descriptor carries its window's parity in bit 0.
@@ -1092,8 +1095,13 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #define BLURRILY_WMT_AT(i_, out_)                                                \
   do {                                                                           \
     const uint32_t p_ = min(BLURRILY_STEP_AT(i_), v1 - 1) * kWPS;                \
-    out_ = A.win_max_tri[p_];                                                    \
-    if (kNib && p_ + 1 < w1) out_ = max(out_, A.win_max_tri[p_ + 1]);            \
+    if (wmt) {                       /* the workgroup's LDS copy (clamped to 255 >= tc): no global round trip */ \
+      out_ = wmt[p_];                                                            \
+      if (kNib && p_ + 1 < w1) out_ = max(out_, uint32_t(wmt[p_ + 1]));          \
+    } else {                                                                     \
+      out_ = A.win_max_tri[p_];                                                  \
+      if (kNib && p_ + 1 < w1) out_ = max(out_, A.win_max_tri[p_ + 1]);          \
+    }                                                                            \
   } while (0)
   // first visit index >= from_ whose step can hold a candidate (n_visit: none)
 #define BLURRILY_NEXT_VISIT(from_, out_)                                         \
@@ -1393,6 +1401,20 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
   const uint32_t tid = threadIdx.x;
 
   for (uint32_t i = tid; i < kCntBytes / 16; i += NT) cnt128[i] = make_uint4(0, 0, 0, 0);
+  // The per-window bound the sweep steps over windows with (win_max_tri) as bytes in LDS, once per workgroup:
+  // the wave that chooses the next step reads it in a dependent loop just before the count barrier, and a global
+  // round trip there is a wait for all sixteen waves (barrier after count: 1 392 of a step's 6 619 clocks).  It
+  // lives in the slice table of the long-needle sweep, which the SHORT instantiations never use; clamped to 255,
+  // exact for the <= 64 trigrams of a needle that gets here.
+  const uint8_t* wmt = nullptr;
+  if constexpr (SHORT && BLURRILY_WMT_IN_LDS) {
+    if (A.n_windows <= 2 * kCodeChunk * 4) {
+      uint8_t* w8 = reinterpret_cast<uint8_t*>(s_tab);
+      for (uint32_t i = tid; i < A.n_windows; i += NT) w8[i] = uint8_t(min(A.win_max_tri[i], 255u));
+      wmt = w8;
+    }
+  }
+  (void)wmt;
   __syncthreads();
 
   const uint32_t n_work = A.n_work_dev ? *A.n_work_dev : A.n_work;
@@ -1458,9 +1480,9 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
       const uint32_t nib_end = !BLURRILY_NIBBLE ? sa : nd.T <= 15 ? sb                                  \
                                : BLURRILY_NIB_PREFIX ? min(sb, max(sa, A.nib_windows)) : sa;            \
       if (nib_end < sb)                                                                                 \
-        sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, nib_end, sb, max(st, nib_end));        \
+        sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, nib_end, sb, max(st, nib_end));        \
       if (sa < nib_end)                                                                                 \
-        sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, sa, nib_end, min(st, nib_end - 1));   \
+        sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, sa, nib_end, min(st, nib_end - 1));   \
     } else if constexpr (SHORT) {                                                                       \
       sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);  \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
