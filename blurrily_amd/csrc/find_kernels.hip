@@ -1066,6 +1066,20 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // stepped over without a barrier), so the producing wave has the table in registers before it
 // needs it.
 constexpr uint32_t kRingUnits = 256;                            // descriptors per ring slot
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two
+// row broadcasts of gfx9): ten VALU instructions, against six dependent ds_bpermute round trips for __shfl_up.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+#define BLURRILY_DPP_ADD(ctrl_, rows_) x += uint32_t(__builtin_amdgcn_update_dpp(0, int(x), ctrl_, rows_, 0xF, false))
+  BLURRILY_DPP_ADD(0x111, 0xF);                                 // row_shr:1
+  BLURRILY_DPP_ADD(0x112, 0xF);                                 // row_shr:2
+  BLURRILY_DPP_ADD(0x114, 0xF);                                 // row_shr:4
+  BLURRILY_DPP_ADD(0x118, 0xF);                                 // row_shr:8
+  BLURRILY_DPP_ADD(0x142, 0xA);                                 // row_bcast:15 -> rows 1 and 3
+  BLURRILY_DPP_ADD(0x143, 0xC);                                 // row_bcast:31 -> rows 2 and 3
+#undef BLURRILY_DPP_ADD
+  return x;
+}
+
 struct UnitRing {
   uint2    desc[2][kRingUnits];                                 // .x first entry of the unit, .y end of its slice
   uint32_t n_units[2];                                          // kRingOverflow: too many units, walk the table
@@ -1134,11 +1148,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #define BLURRILY_PRODUCE(s_, A0, B0, A1, B1)                                     \
   do {                                                                           \
     const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
-    uint32_t incl_ = units0_ + units1_;                                          \
-    _Pragma("unroll") for (uint32_t d_ = 1; d_ < 64; d_ <<= 1) {                 \
-      const uint32_t up_ = __shfl_up(incl_, d_);                                 \
-      if (lane >= d_) incl_ += up_;                                              \
-    }                                                                            \
+    const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
     if (total_ > kRingUnits) {                                                   \
       if (lane == 0) ring->n_units[s_] = kRingOverflow;                          \
