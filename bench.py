@@ -8,7 +8,9 @@ synthetic needles that is already resident in HBM.  At N=1 the workload is
 BASELINE.json configs[2]: the synthetic Geonames-scale haystack (8 423 769 multi-word strings,
 ~118 M trigram entries) and one batch of 1 M needles.  For N>1 (configs[3]) the haystack is
 replicated on every GPU, every rank gets its own 1 M-needle shard (weak scaling) and the
-per-rank result blocks are collected on rank 0 by ONE RCCL gather inside the timed region.
+per-rank result blocks are collected on rank 0 by ONE RCCL gather per step inside the timed region --
+issued asynchronously, so that it travels over xGMI while the next step is searched into a second
+block; the region ends only when every gather has arrived.
 
 Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carries
 
@@ -187,37 +189,53 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     d_off = torch.from_numpy(qo.astype(np.int64)).to(dev)
     # this rank's results are ONE buffer (rows | counts) that the kernels fill in place and that the
     # gather ships as it is (blurrily_amd/sharding.py)
-    block = ResultBlock(n_q, limit, device=dev)
+    # N > 1: two blocks by turns, so that the gather of one step's results travels (RCCL's own stream) while the
+    # next step is being searched; every gather is waited for inside the timed region (fence)
+    blocks = [ResultBlock(n_q, limit, device=dev) for _ in range(2 if world > 1 else 1)]
+    block = blocks[0]
     d_nb = torch.empty((n_q,), dtype=torch.int32, device=dev)
-    gathered = None
     host_gather = world > 1 and dist.get_backend() != "nccl"      # (smoke-test mode, see main)
+    gathered = [None, None]
     if world > 1 and rank == 0:
-        gathered = torch.empty((world, block.buf.numel()), dtype=torch.int32, device="cpu" if host_gather else dev)
+        gathered = [torch.empty((world, block.buf.numel()), dtype=torch.int32, device="cpu" if host_gather else dev)
+                    for _ in range(2)]
+    in_flight = [None, None]                                      # (work handle, tensors it still reads) per block
+    step_no = [0]
     lib = _native.lib()
     m.set_timing(True)
     stream = torch.cuda.current_stream().cuda_stream
     kernel_ms, gather_ms = [], []
 
-    def find():
+    def find(into=None):
+        b = block if into is None else into
         res = lib.blurrily_storage_find_batch_device(
             m.handle, d_packed.data_ptr(), int(qo[-1]), d_off.data_ptr(), n_q, limit,
-            block.rows.data_ptr(), block.counts.data_ptr(), d_nb.data_ptr(), stream)
+            b.rows.data_ptr(), b.counts.data_ptr(), d_nb.data_ptr(), stream)
         if res < 0:
             raise RuntimeError(f"find_batch_device failed: errno {C.get_errno()}")
 
+    def settle(i):
+        if in_flight[i] is not None:
+            in_flight[i][0].wait()
+            in_flight[i] = None
+
     def step():
-        find()
+        i = step_no[0] % len(blocks)
+        step_no[0] += 1
+        t = time.perf_counter()
+        settle(i)                                                    # the gather that last read this block
+        waited = time.perf_counter() - t
+        find(blocks[i])
         kernel_ms.append(m.device_info()["last_find_kernel_ms"])     # (timing mode: the call has synchronised)
         if world > 1:
             t = time.perf_counter()
-            if host_gather:
-                gather_blocks(dist, ResultBlock(n_q, limit, buf=block.buf.cpu()), gathered, rank)
-            else:
-                gather_blocks(dist, block, gathered, rank)
-            torch.cuda.synchronize()
-            gather_ms.append(1e3 * (time.perf_counter() - t))
+            src = ResultBlock(n_q, limit, buf=blocks[i].buf.cpu()) if host_gather else blocks[i]
+            in_flight[i] = (gather_blocks(dist, src, gathered[i], rank, async_op=True), src)
+            gather_ms.append(1e3 * (time.perf_counter() - t + waited))   # what the step saw of it
 
     def fence():
+        for i in range(len(blocks)):
+            settle(i)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -239,7 +257,15 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
         elapsed = float(t.item())
 
     # ---- derived figures (outside the timed region) ----------------------------------------
-    # rows of the LAST TIMED launch, for the parity leg
+    # rank 0's own slot of every gathered buffer must be the block it was sent from: the blocks go round by
+    # turns, and a gather overtaken by the next search would show here
+    gather_checked = 0
+    if world > 1 and rank == 0:
+        for j in range(min(len(blocks), steps + warmup)):
+            if not torch.equal(gathered[j][0].cpu(), blocks[j].buf.cpu()):
+                raise RuntimeError(f"gathered block {j} differs from the block it was sent from")
+            gather_checked += 1
+    # rows of the LAST TIMED launch, for the parity leg (every launch searches the same batch: both blocks hold them)
     gpu_rows = block.rows.cpu().numpy().view(np.uint32)
     gpu_counts = block.counts.cpu().numpy().view(np.uint32)
     nb = d_nb.cpu().numpy().astype(np.uint32).astype(np.int64)
@@ -347,6 +373,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             out["per_rank"] = {"kernel_ms": [p[1] for p in per_rank], "gather_ms": [p[2] for p in per_rank]}
             out["gather_ms"] = float(np.mean(gather_ms))
             out["gather_bytes_per_rank"] = int(block.buf.numel() * 4)
+            out["gather_overlapped"] = True     # gather_ms = what a step saw of the collective (issue + waits)
+            out["gather_checked"] = gather_checked
         if world == 1 and cpu_budget > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(m, hay, hay_off, qp, qo, limit, cpu_budget, gpu_rows, gpu_counts)

@@ -36,15 +36,17 @@ class ResultBlock:
         self.counts = self.buf[self.n * self.limit * 3:]
 
 
-def gather_blocks(dist, block, gathered, rank, dst=0):
+def gather_blocks(dist, block, gathered, rank, dst=0, async_op=False):
     """THE collective of the path: every rank's block to rank `dst` in one gather.
 
     `block` is a ResultBlock (all ranks: same n and limit -- pad the last shard); `gathered` is
-    an int32 tensor [world, words] on `dst` (None elsewhere)."""
+    an int32 tensor [world, words] on `dst` (None elsewhere).  With `async_op` the call returns the
+    collective's work handle at once: the gather of one batch then travels over xGMI while the next
+    batch is being searched (into another block -- `block` and `gathered` stay the collective's until
+    `wait()`)."""
     if rank == dst:
-        dist.gather(block.buf, gather_list=list(gathered.unbind(0)), dst=dst)
-    else:
-        dist.gather(block.buf, gather_list=None, dst=dst)
+        return dist.gather(block.buf, gather_list=list(gathered.unbind(0)), dst=dst, async_op=async_op)
+    return dist.gather(block.buf, gather_list=None, dst=dst, async_op=async_op)
 
 
 def find_batch_sharded(dist, find_fn, needles, limit, rank, world, dst=0, device=None):

@@ -133,4 +133,6 @@ def test_bench_two_ranks_plumbing(tmp_path):
     assert abs(d["value"] - 2 * 50000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6      # whole-job needles/s
     assert len(d["per_rank"]["kernel_ms"]) == 2 and len(d["per_rank"]["gather_ms"]) == 2
     assert d["gather_bytes_per_rank"] == 50000 * (10 * 12 + 4) and d["gather_ms"] > 0
+    # the gathers overlap the next step's search: both blocks went round and arrived as they were sent
+    assert d["gather_overlapped"] is True and d["gather_checked"] == 2
     assert "cpu_baseline" not in d and "extra_configs" not in d
