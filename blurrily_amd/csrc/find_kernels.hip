@@ -713,7 +713,10 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       v = S::mask_pad(v, i);
       // one SWAR test per vector: the top bit of a field is set iff its counter >= need
 #if BLURRILY_SCAN_PREFILTER
-      if (S::maybe(v, nq) && S::any_hit(v, nq)) harvest(v, i);
+      if (S::maybe(v, nq) && S::any_hit(v, nq)) {
+        __builtin_amdgcn_s_setprio(3);     // a wave that found something is the one the scan barrier will wait for
+        harvest(v, i);
+      }
 #else
       if (S::any_hit(v, nq)) harvest(v, i);
 #endif
@@ -734,6 +737,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
 #endif
   }
   S::clear_unreached_pad(cnt128, nvec, tid);
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // Cold start: with no threshold yet, every non-zero counter of a window would flood the pool
@@ -1260,6 +1264,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     ++st_steps;
     PHASE_MARK(0);                                              // loop overhead
     // ---- count step p --------------------------------------------------------------------
+    // (the two waves with a turn to take behind their units are the ones the count barrier waits for: they
+    // issue ahead of the others from the start of the step)
+    const bool has_turn = wid == BLURRILY_PRODUCER(e + 1) || wid == BLURRILY_PRODUCER(e + 2);
+    if (has_turn) __builtin_amdgcn_s_setprio(2);
     if (n_units == kRingOverflow) {
       BLURRILY_COUNT_WALK(p);
     } else {
@@ -1268,21 +1276,25 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     PHASE_MARK(2);                                              // units counted
     // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
     if (wid == BLURRILY_PRODUCER(e + 1)) {
+      __builtin_amdgcn_s_setprio(3);                            // the wave the count barrier waits for goes first
       if (my_i < n_visit) {
         BLURRILY_PRODUCE(s ^ 1u, ta, tb, ta1, tb1);
         if (lane == 0) ring->step[s ^ 1u] = BLURRILY_STEP_AT(my_i);
       } else if (lane == 0) {
         ring->n_units[s ^ 1u] = 0; ring->step[s ^ 1u] = v1;
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     PHASE_MARK(7);                                              // (producer turn) next step's units published
     // the wave after it chooses the step after the next (the threshold only changes behind select's
     // barriers) and fetches its table, which travels during the barrier and the scan
     if (wid == BLURRILY_PRODUCER(e + 2)) {
+      __builtin_amdgcn_s_setprio(3);
       const uint32_t chosen = __builtin_amdgcn_readfirstlane(ring->visit[(e + 1) & 1]);
       BLURRILY_NEXT_VISIT(chosen + 1, my_i);
       if (lane == 0) ring->visit[e & 1] = my_i;
       BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);
+      __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();                                            // counts and next descriptors visible
     PHASE_MARK(3);                                              // barrier after count
