@@ -656,6 +656,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
   const uint32_t tid = threadIdx.x;
   const uint32_t need = max(matches_needed(thr, nd.T, wbase), need_floor);
   const uint32_t nvec = S::nvec(wlen);
+  __builtin_amdgcn_s_setprio(1);                         // the scan is a chain of LDS round trips: it goes ahead of the other workgroup's counting
   if (need <= min(nd.T, S::kMaxCount)) {                 // (a 4-bit window holds no counter above 15)
     const typename S::Need nq = S::prepare(need);
     // slow path of one vector: some counter reached `need`
