@@ -102,6 +102,9 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 #ifndef BLURRILY_WMT_IN_LDS
 #define BLURRILY_WMT_IN_LDS 1          // the per-window bound as bytes in LDS (find_kernel), read by the step-choosing wave
 #endif
+#ifndef BLURRILY_SERIAL_PRIO
+#define BLURRILY_SERIAL_PRIO 2           // wave priority in a workgroup's serial sections (between needles, compaction, cold start)
+#endif
 #define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
 #endif
 #ifndef BLURRILY_CLEAR_WRITE2
@@ -561,6 +564,7 @@ __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uin
 // threshold.  Called by all threads of the workgroup.
 template <int NT>
 __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t cap, uint32_t keep) {
+  __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);            // barriers and LDS round trips, nothing to overlap inside the workgroup
   const uint32_t tid = threadIdx.x;
   const uint32_t n = min(ctl->pool_n, cap);
   if (BLURRILY_RANK_SORT_MAX && n <= BLURRILY_RANK_SORT_MAX) {
@@ -580,6 +584,7 @@ __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t ca
       if (n >= keep && keep > 0) ctl->thr = pool[keep - 1];
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     return;
   }
   uint32_t P = 1;
@@ -604,6 +609,7 @@ __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t ca
     if (n >= keep && keep > 0) ctl->thr = pool[keep - 1];
   }
   __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // State of one needle's sweep that every phase needs.
@@ -753,6 +759,7 @@ __device__ __forceinline__ uint32_t cold_start_need(const uint4* cnt128, uint32_
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t nvec = S::nvec(wlen);
   uint32_t lo = 1, hi = min(T, S::kMaxCount);            // answer in [lo, hi]; lo = 1 means "no restriction"
+  __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (tid == 0) ctl->tally = 0;
@@ -1444,6 +1451,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
   PHASE_NEEDLE_DECL;
   for (;;) {
+    __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);        // between two needles: one chain of round trips
     if (tid == 0) ctl->q = atomicAdd(A.queue, 1u);
     __syncthreads();
     const uint32_t slot = ctl->q;
@@ -1490,6 +1498,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     __syncthreads();
 
     PHASE_NEEDLE(10);
+    __builtin_amdgcn_s_setprio(0);
     if (STATS(A) && tid == 0) atomicAdd(&STATS(A)[kStatTasks], 1ull);
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
@@ -1534,6 +1543,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
     compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+    __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);
     const uint32_t nres = ctl->pool_n;
     if (RANGED) {
       // latency mode: leave this range's best keys for merge_parts_kernel
