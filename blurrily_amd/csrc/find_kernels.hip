@@ -433,9 +433,8 @@ struct Control {            // workgroup-shared scalars
 };
 
 // One posting = one relaxed LDS atomic (result unused -> ds_add_u32) on the word holding the
-// rank's counter.  The address and the increment are formed in three instructions per posting: and (address), shift (bit position; the hardware
-// uses the low five bits of a shift amount), shift (increment).  For the rank in the high half
-// of a loaded dword the first two read that half directly (SDWA operand select).
+// rank's counter.  This is the generic form (16-bit counters); byte and 4-bit counters take the
+// packed-dword path below (bump_pair_bytes: 2 + 3 VALU instructions per pair of postings).
 template <typename CT>
 __device__ __forceinline__ void bump(uint32_t* cnt32, uint32_t r) {
   using P = Packing<CT>;
