@@ -93,3 +93,50 @@ def test_world_size_2_gather_reassembles_in_order(tmp_path, n_needles):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, _free_port(), n_needles, 5, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def _pipelined_worker(rank, world, port, steps, out_path):
+    """bench.py's N > 1 loop in miniature: two blocks by turns, the gather of one step in flight while the next
+    step fills the other block, a block reused only behind its gather's wait()."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from blurrily_amd.sharding import gather_blocks
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, limit = 50, 4
+    blocks = [ResultBlock(n, limit), ResultBlock(n, limit)]
+    gathered = [torch.empty((world, blocks[0].buf.numel()), dtype=torch.int32) if rank == 0 else None for _ in range(2)]
+    in_flight = [None, None]
+    seen = []
+    for step in range(steps):
+        i = step % 2
+        if in_flight[i] is not None:
+            in_flight[i].wait()
+            if rank == 0:
+                seen.append((step - 2, gathered[i].clone()))
+        blocks[i].rows[:] = 1000 * step + rank                 # "the search": every step writes different rows
+        blocks[i].counts[:] = step
+        in_flight[i] = gather_blocks(dist, blocks[i], gathered[i], rank, async_op=True)
+    for k in range(2):                                          # the fence of the timed region
+        i = (steps + k) % 2
+        if in_flight[i] is not None:
+            in_flight[i].wait()
+            if rank == 0:
+                seen.append((steps - 2 + k, gathered[i].clone()))
+    if rank == 0:
+        ok = sorted(s for s, _ in seen) == list(range(steps))
+        for step, g in seen:
+            for r in range(world):
+                peer = ResultBlock(n, limit, buf=g[r])
+                ok = ok and bool((peer.rows == 1000 * step + r).all()) and bool((peer.counts == step).all())
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gathers_overlap_the_next_step(tmp_path):
+    out = tmp_path / "result.txt"
+    mp.spawn(_pipelined_worker, args=(2, _free_port(), 5, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
