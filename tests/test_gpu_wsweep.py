@@ -150,7 +150,10 @@ def test_small_batches_and_small_haystacks_keep_the_needle_major_path(ws_env):
     _check_all(m, o, q, qo, 10, took_ws=False)
 
 
-@pytest.mark.parametrize("seed", range(6))
+_FUZZ_FIRST = int(os.environ.get("BLURRILY_FUZZ_FIRST", "0"))           # soak runs: BLURRILY_FUZZ_FIRST=6 BLURRILY_FUZZ_SEEDS=40
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("BLURRILY_FUZZ_SEEDS", "6"))))
 def test_randomised_window_major_configurations(ws_env, seed):
     """Seeded random configurations of the window-major sweep -- haystack kind and size (5 to 11 windows),
     limit, cmin, reference numbering (dense / sparse), a sprinkle of deletes -- every row against the oracle."""
