@@ -357,7 +357,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # in-kernel (blurrily_storage_set_stats) in an extra untimed launch of THIS run; L2 hits included
                 "requested_bytes": req_bytes, "requested_gbs": req_gbs,
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if st["probes"] else
-                           "find_kernel<uint8_t,%s>" % os.environ.get("BLURRILY_FIND_THREADS", "1024")),
+                           "find_kernel<uint8_t,1024>"),
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_gbs": algo_bytes / (k_ms * 1e-3) / 1e9,
@@ -421,7 +421,8 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # every rank builds the same (seeded) haystack: share the host's cores between the ranks
-        os.environ.setdefault("BLURRILY_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
+        from blurrily_amd.map import set_process_option
+        set_process_option("host_threads", max(1, (os.cpu_count() or 1) // world))
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:

@@ -8,7 +8,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BLURRILY_LIB selects another build of the same library (the phase-profile build of tools/)
+# BLURRILY_LIB selects another build of the same library (same-box A/B of two builds, tools/ab_probe.py)
 LIB_PATH = os.environ.get("BLURRILY_LIB") or os.path.join(_HERE, "libblurrily_hip.so")
 
 
@@ -103,6 +103,8 @@ def lib():
         "blurrily_storage_set_timing": (None, [vp, C.c_int]),
         "blurrily_storage_set_stats": (None, [vp, C.c_int]),
         "blurrily_storage_find_stats": (C.c_int, [vp, C.c_void_p]),
+        "blurrily_storage_set_option": (C.c_int, [vp, C.c_char_p, C.c_longlong]),
+        "blurrily_storage_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_longlong)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -120,4 +122,5 @@ EXPORTED_SYMBOLS = (
     "blurrily_storage_sync_device", "blurrily_tokeniser_parse_string",
     "blurrily_storage_device_info", "blurrily_storage_set_timing",
     "blurrily_storage_set_stats", "blurrily_storage_find_stats",
+    "blurrily_storage_set_option", "blurrily_storage_get_option",
 )

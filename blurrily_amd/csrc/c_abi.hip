@@ -93,10 +93,15 @@ struct trigram_map_t {
   DeviceIndex delta;                    // image of `pending` only
   uint32_t*   d_code_total_now = nullptr;   // [kNumCodes] bucket sizes of the whole map (base run's nb_entries)
   DeviceBuffer ws_base_rows, ws_base_counts, ws_delta_rows, ws_delta_counts;
+  // tunables of the window-major sweep (blurrily_storage_set_option; defaults from the measured gate)
+  IndexBuildOptions build_opt;          // ws_enabled, ws_min_windows, ws_min_slice, dense_min
+  uint32_t    ws_cmin = 3;              // a left-out slice must leave at least this many counted matches
+  uint32_t    ws_min_needles = 16384;   // smaller batches: needle-major
   int         n_cus = 0;
   bool        timing = false;
   bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
   unsigned long long* d_stats = nullptr;   // [kStatSlots], zeroed by every run_find while collecting
+  unsigned long long* d_phase = nullptr;   // [kPhaseWorkgroups][16] phase clocks of the counted build's last launch
   double      last_find_ms = 0.0, last_tok_ms = 0.0;
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_in, ws_io_out;
@@ -104,10 +109,6 @@ struct trigram_map_t {
 };
 
 namespace {
-
-#ifdef BLURRILY_PHASE_PROFILE
-unsigned long long* g_phase_clocks = nullptr;
-#endif
 
 size_t log_budget(const trigram_map m) { return std::max<size_t>(4096, m->dev.n_refs / 64); }
 
@@ -130,8 +131,11 @@ bool log_empty(const trigram_map m) { return m->pending.empty() && m->n_tomb == 
 // 1/64 of the base (or 4096 mutations) triggers a full rebuild.
 int ensure_device(trigram_map m) {
   const bool have_base = m->dev.device >= 0;
-  if (!have_base || m->log_overflow || m->pending.size() + m->n_tomb > log_budget(m)) {
-    if (device_index_build(*m->host, &m->dev) < 0) return -1;
+  // (an option changed so that the window-major sweep may now run on an image built without bitmaps: rebuild)
+  const bool lacks_bitmaps = have_base && !m->dev.d_bm_id &&
+                             m->build_opt.wants_bitmaps(m->dev.n_windows, m->dev.mean_hit_slice);
+  if (!have_base || lacks_bitmaps || m->log_overflow || m->pending.size() + m->n_tomb > log_budget(m)) {
+    if (device_index_build(*m->host, &m->dev, m->build_opt) < 0) return -1;
     ++m->base_builds;
     clear_log(m);
     if (m->n_cus == 0) {
@@ -147,7 +151,7 @@ int ensure_device(trigram_map m) {
   if (m->delta_image_version != m->delta_puts_version) {
     if (m->pending.empty()) {
       if (m->delta.device >= 0) device_index_free(&m->delta);
-    } else if (device_index_build(*m->delta_host, &m->delta) < 0) {
+    } else if (device_index_build(*m->delta_host, &m->delta, m->build_opt) < 0) {
       return -1;
     }
     m->delta_image_version = m->delta_puts_version;
@@ -170,9 +174,13 @@ void log_put(trigram_map m, const char* needle, size_t len, uint32_t ref, uint32
     m->log_overflow = true;
     return;
   }
-  m->pending[ref] = PendingPut{std::string(needle, len), weight};
   if (!m->delta_host) m->delta_host = new HostIndex();
-  m->delta_host->put(needle, len, ref, weight);
+  if (m->delta_host->put(needle, len, ref, weight) < 0) {   // (out of memory) the delta image would miss it:
+    m->pending.clear();                                     // fold everything into a rebuilt base instead
+    m->log_overflow = true;
+    return;
+  }
+  m->pending[ref] = PendingPut{std::string(needle, len), weight};
   ++m->delta_puts_version;
   ++m->log_version;
 }
@@ -199,34 +207,21 @@ int apply_tombstones(trigram_map m, hipStream_t stream) {
   if (m->tomb_queue.empty()) return 0;
   const size_t n = m->tomb_queue.size();
   if (m->ws_tomb.reserve(n * sizeof(uint32_t), stream) < 0) return -1;
-  // (pageable source: the runtime stages it before returning, the queue can be cleared right away)
-  BLURRILY_HIP_TRY(hipMemcpyAsync(m->ws_tomb.p, m->tomb_queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                  stream));
+  // Deletes are rare on this path: a synchronous copy (the queue may be cleared when it returns, whatever the
+  // runtime does with a pageable source), the kernel on the find's stream, and a wait for it -- so that the bits
+  // are set for every stream and for device_info / debug reads, not only for finds on this one.
+  BLURRILY_HIP_TRY(hipMemcpy(m->ws_tomb.p, m->tomb_queue.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(apply_tombstones_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, stream, m->dev.d_tomb,
                      static_cast<const uint32_t*>(m->ws_tomb.p), uint32_t(n));
   BLURRILY_HIP_TRY(hipGetLastError());
+  BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
   m->tomb_queue.clear();
   return 0;
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Tunables of the window-major sweep (environment, read at every find call): BLURRILY_WSWEEP=0 turns it off;
-// BLURRILY_WS_CMIN (default 3, measured best) is the least number of counted matches a left-out slice must leave;
-// BLURRILY_WS_MIN_WINDOWS / BLURRILY_WS_MIN_NEEDLES / BLURRILY_WS_MIN_SLICE bound the haystacks and
-// batches it is used for.
-uint32_t env_u32(const char* name, uint32_t dflt) {
-  const char* e = std::getenv(name);
-  return e && *e ? uint32_t(std::strtoul(e, nullptr, 10)) : dflt;
-}
-bool     ws_enabled()     { return env_u32("BLURRILY_WSWEEP", 1) != 0; }
-uint32_t ws_cmin()        { return std::max(1u, env_u32("BLURRILY_WS_CMIN", 3)); }
-uint32_t ws_min_windows() { return env_u32("BLURRILY_WS_MIN_WINDOWS", 8); }
-uint32_t ws_min_needles() { return env_u32("BLURRILY_WS_MIN_NEEDLES", 16384); }
-// BLURRILY_WS_MIN_SLICE: least DeviceIndex::mean_hit_slice.  Measured on MI355X (tools/ws_probe.py): at
-// 7 000 (configs[4], hot-trigram haystack) the window-major sweep is 1.4x the needle-major one, at 1 300
-// (configs[2], Geonames scale) it is 0.77x -- its fixed cost per (needle, window) is not yet paid back.
-uint32_t ws_min_slice()   { return env_u32("BLURRILY_WS_MIN_SLICE", 3000); }
+constexpr size_t kPhaseWorkgroups = 8192, kPhaseBytes = kPhaseWorkgroups * 16 * 8;
 constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for small host-buffer batches
 
 // the timed build of the kernels, or (while request counters are collected) the counted one
@@ -280,15 +275,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   a.tomb = d_tomb;
   a.stats = m->collect_stats ? m->d_stats : nullptr;
   const bool cb = a.stats != nullptr;
-#ifdef BLURRILY_PHASE_PROFILE
-  {
-    static unsigned long long* d_phase = nullptr;
-    if (!d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_phase), 8192 * 16 * 8));
-    BLURRILY_HIP_TRY(hipMemsetAsync(d_phase, 0, 8192 * 16 * 8, stream));
-    a.phase_clocks = d_phase;
-    g_phase_clocks = d_phase;
+  if (cb) {                                          // wave 0's phase clocks per workgroup (counted build only)
+    if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
+    BLURRILY_HIP_TRY(hipMemsetAsync(m->d_phase, 0, kPhaseBytes, stream));
+    a.phase_clocks = m->d_phase;
   }
-#endif
   // every launch gets its own zeroed queue word (scalars[2..63]); recycled in stream order
   uint32_t queue_slot = 2;
   auto next_queue = [&]() -> uint32_t* {
@@ -341,13 +332,14 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // Large batches over many windows: the window-major sweep (find_kernels.hip, wsweep_kernel).
     // Phase 1 -- the needle-major kernel over the window pair of every needle's own length class --
     // seeds the needles' states; one launch per window follows; keys become rows at the end.
-    const bool use_ws = ranges <= 1 && ws_enabled() && limit <= kWsMaxKeep && ix.n_windows >= ws_min_windows() &&
-                        n >= ws_min_needles() && ix.d_bm_id != nullptr && code_slots < 0xFFFFFFFFull &&
-                        ix.mean_hit_slice >= double(ws_min_slice());
+    // (which images it runs on -- enough windows, slices big enough to pay a task's fixed cost back --
+    // is IndexBuildOptions::wants_bitmaps: an image it cannot run on carries no bitmaps)
+    const bool use_ws = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.d_bm_id != nullptr &&
+                        m->build_opt.wants_bitmaps(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
     if (use_ws) {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
-      a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = ws_cmin();
+      a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = m->ws_cmin;
       // Phase 1: the needle-major kernel over the window pair of every needle's own length class seeds the
       // states (a needle's best matches live there, so its threshold is tight before the other windows are
       // visited).  (Seeding through wsweep_kernel's own robust path instead -- own_pass launches -- was
@@ -477,6 +469,7 @@ int blurrily_storage_close(trigram_map* haystack) {
     delete m->delta_host;
     if (m->d_code_total_now) (void)hipFree(m->d_code_total_now);
     if (m->d_stats) (void)hipFree(m->d_stats);
+    if (m->d_phase) (void)hipFree(m->d_phase);
     m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
@@ -697,6 +690,64 @@ void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabl
 
 void blurrily_storage_set_stats(trigram_map m, int enabled) { m->collect_stats = enabled != 0; }
 
+// Tunables: one table, so that set and get cannot drift apart.  A map's options are plain fields read by its
+// next find (calls on one map are serial, as in the reference: no lock); the process-wide ones are atomics.
+namespace {
+struct OptionSlot { const char* key; long long lo, hi; };
+constexpr OptionSlot kMapOptions[] = {
+    {"wsweep", 0, 1}, {"ws_cmin", 1, 64}, {"ws_min_windows", 0, 1 << 20}, {"ws_min_needles", 0, 1ll << 32},
+    {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}};
+constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
+int find_option(const OptionSlot* tab, size_t n, const char* key) {
+  for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
+  return -1;
+}
+#define FIND_OPTION(tab, key) find_option(tab, sizeof(tab) / sizeof(tab[0]), key)
+}  // namespace
+
+int blurrily_storage_set_option(trigram_map m, const char* key, long long value) {
+  if (!key) { errno = EINVAL; return -1; }
+  if (!m) {
+    const int i = FIND_OPTION(kProcessOptions, key);
+    if (i < 0 || value < kProcessOptions[i].lo || value > kProcessOptions[i].hi) { errno = EINVAL; return -1; }
+    if (i == 0) set_host_threads(unsigned(value)); else set_build_trace(value != 0);
+    return 0;
+  }
+  const int i = FIND_OPTION(kMapOptions, key);
+  if (i < 0 || value < kMapOptions[i].lo || value > kMapOptions[i].hi) { errno = EINVAL; return -1; }
+  switch (i) {
+    case 0: m->build_opt.ws_enabled = value != 0; break;
+    case 1: m->ws_cmin = uint32_t(value); break;
+    case 2: m->build_opt.ws_min_windows = uint32_t(value); break;
+    case 3: m->ws_min_needles = uint32_t(std::min<long long>(value, 0xFFFFFFFFll)); break;
+    case 4: m->build_opt.ws_min_slice = uint32_t(value); break;
+    case 5:                                        // which slices have bitmaps: the image is rebuilt by the next find
+      if (m->build_opt.dense_min != uint32_t(value) && m->dev.device >= 0) m->log_overflow = true;
+      m->build_opt.dense_min = uint32_t(value);
+      break;
+  }
+  return 0;
+}
+
+int blurrily_storage_get_option(trigram_map m, const char* key, long long* value) {
+  if (!key || !value) { errno = EINVAL; return -1; }
+  if (!m) {
+    const int i = FIND_OPTION(kProcessOptions, key);
+    if (i < 0) { errno = EINVAL; return -1; }
+    *value = i == 0 ? (long long)host_threads() : (long long)build_trace();
+    return 0;
+  }
+  switch (FIND_OPTION(kMapOptions, key)) {
+    case 0: *value = m->build_opt.ws_enabled; return 0;
+    case 1: *value = m->ws_cmin; return 0;
+    case 2: *value = m->build_opt.ws_min_windows; return 0;
+    case 3: *value = m->ws_min_needles; return 0;
+    case 4: *value = m->build_opt.ws_min_slice; return 0;
+    case 5: *value = m->build_opt.dense_min; return 0;
+    default: errno = EINVAL; return -1;
+  }
+}
+
 // debugging aid (tools/ws_probe.py): all counter slots, phase clocks of the window-major sweep included
 int blurrily_debug_find_stats16(trigram_map m, uint64_t* out16) {
   std::memset(out16, 0, kStatAllSlots * 8);
@@ -716,13 +767,14 @@ int blurrily_storage_find_stats(trigram_map m, uint64_t* out8) {
   return 0;
 }
 
-#ifdef BLURRILY_PHASE_PROFILE
-// profiling builds only: copy out the per-workgroup phase clocks of the last find launch
-int blurrily_debug_phase_clocks(unsigned long long* out, size_t n_workgroups) {
-  if (!g_phase_clocks) return -1;
-  (void)hipDeviceSynchronize();
-  return hipMemcpy(out, g_phase_clocks, n_workgroups * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+// debugging aid (tools/phase_profile.py): per-workgroup phase clocks of the last find launched while
+// blurrily_storage_set_stats was on
+int blurrily_debug_phase_clocks(trigram_map m, unsigned long long* out, size_t n_workgroups) {
+  if (!m->d_phase || n_workgroups > kPhaseWorkgroups) { errno = EINVAL; return -1; }
+  DeviceScope scope(m->dev.device);
+  BLURRILY_HIP_TRY(hipDeviceSynchronize());
+  BLURRILY_HIP_TRY(hipMemcpy(out, m->d_phase, n_workgroups * 16 * 8, hipMemcpyDeviceToHost));
+  return 0;
 }
-#endif
 
 }  // extern "C"

@@ -41,10 +41,7 @@
 
 namespace blurrily {
 
-#ifndef BLURRILY_WINDOW_BITS
-#define BLURRILY_WINDOW_BITS 16          // (15 -- half the counters, 4 workgroups of 512 per CU -- was measured slower; find_kernels.hip now assumes 16)
-#endif
-constexpr uint32_t kWindowBits  = BLURRILY_WINDOW_BITS;
+constexpr uint32_t kWindowBits  = 16;   // (15 -- half the counters, 4 workgroups of 512 per CU -- was measured slower; find_kernels.hip assumes 16)
 constexpr uint32_t kWindowSize  = 1u << kWindowBits;    // counter slots per window (LDS)
 // Ranks per window: the last 16 counter slots stay free of references -- slot 0xFFFF is the padding
 // sentinel's, and with the other 15 unused as well the needle-major scan never has to read (and mask)
@@ -55,10 +52,7 @@ constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byt
 // A (window, code) slice with at least this many postings also exists as a BITMAP of the window
 // (kWindowSize bits = 8 KiB; bit r set iff in-window rank r holds the code): the window-major sweep
 // leaves such slices out of the count and asks the bitmap about the few ranks that matter instead.
-#ifndef BLURRILY_DENSE_MIN
-#define BLURRILY_DENSE_MIN 1024
-#endif
-constexpr uint32_t kDenseMin     = BLURRILY_DENSE_MIN;
+constexpr uint32_t kDenseMin     = 1024;                // default of IndexBuildOptions::dense_min
 constexpr uint32_t kBitmapWords  = kWindowSize / 32;    // u32 words per bitmap
 constexpr uint32_t kNoBitmap     = 0xFFFFFFFFu;
 
@@ -93,12 +87,25 @@ struct DeviceIndex {
   std::vector<uint32_t> h_rank_of_pos;    // rank of h_sorted_ref[i]
 };
 
+// What the window-major sweep needs of an image (blurrily_storage_set_option; c_abi.hip holds the per-map copy).
+// Bitmaps of dense slices cost host time, upload and HBM (Geonames scale: 143 MB + an 11 MB id table), so an
+// image gets them only when the sweep can run on it at all.
+struct IndexBuildOptions {
+  bool     ws_enabled     = true;
+  uint32_t ws_min_windows = 8;      // fewer windows: the needle-major sweep is taken whatever the batch
+  uint32_t ws_min_slice   = 3000;   // least DeviceIndex::mean_hit_slice (measured gate)
+  uint32_t dense_min      = kDenseMin;
+  bool wants_bitmaps(uint32_t n_windows, double mean_hit_slice) const {
+    return ws_enabled && n_windows >= ws_min_windows && mean_hit_slice >= double(ws_min_slice);
+  }
+};
+
 // Build the device image of `host` on the current HIP device.  Returns 0, or
 // -1 with errno: ENODEV (no device), ENOMEM, EPROTO (postings violate the
 // invariants put() guarantees: duplicate reference inside a bucket, a
 // reference with two different weights, a reference missing from the leading
 // buckets).
-int  device_index_build(const HostIndex& host, DeviceIndex* out);
+int  device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuildOptions& opt = IndexBuildOptions());
 void device_index_free(DeviceIndex* ix);
 // Rank of `ref` in the device image, or -1 if the image does not hold it.
 int64_t device_index_rank_of(const DeviceIndex& ix, uint32_t ref);

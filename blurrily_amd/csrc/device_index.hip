@@ -94,7 +94,7 @@ void device_index_free(DeviceIndex* ix) {
   *ix = DeviceIndex();
 }
 
-int device_index_build(const HostIndex& host, DeviceIndex* out) {
+int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuildOptions& opt) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     std::fprintf(stderr, "blurrily_hip: no usable HIP device (find has no CPU fallback)\n");
@@ -104,7 +104,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   int dev = 0;
   BLURRILY_HIP_TRY(hipGetDevice(&dev));
   // BLURRILY_BUILD_TRACE=1: wall time of every build stage on stderr
-  const bool trace = std::getenv("BLURRILY_BUILD_TRACE") != nullptr;
+  const bool trace = build_trace();
   auto t_last = std::chrono::steady_clock::now();
   auto stage = [&](const char* what) {
     if (!trace) return;
@@ -283,12 +283,19 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum; dense slices get a
   // bitmap number (in slice order: the image does not depend on thread timing)
   uint64_t n_slots = 0;
-  uint32_t dense_min = kDenseMin;                          // (BLURRILY_DENSE_MIN: tuning experiments)
-  if (const char* e = std::getenv("BLURRILY_DENSE_MIN")) dense_min = std::max(64u, uint32_t(std::atoi(e)));
-  std::vector<uint32_t> bm_id(n_slices, kNoBitmap);
+  // (only when the window-major sweep can run on this image at all: no bitmaps, no id table otherwise)
+  double mean_hit_slice = 0.0;
+  {
+    double sq = 0.0;
+    for (uint32_t t = 0; t < kNumCodes; ++t) sq += double(code_total[t]) * double(code_total[t]);
+    mean_hit_slice = nnz ? sq / double(nnz) / double(n_win) : 0.0;
+  }
+  const bool with_bitmaps = opt.wants_bitmaps(n_win, mean_hit_slice);
+  const uint32_t dense_min = std::max(64u, opt.dense_min);
+  std::vector<uint32_t> bm_id(with_bitmaps ? n_slices : 0, kNoBitmap);
   uint32_t n_bitmaps = 0;
   for (uint64_t i = 0; i < n_slices; ++i) {
-    if (slice_off[i + 1] >= dense_min) bm_id[i] = n_bitmaps++;
+    if (with_bitmaps && slice_off[i + 1] >= dense_min) bm_id[i] = n_bitmaps++;
     const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
     n_slots += len;
     if (n_slots > 0xFFFF0000ull) { errno = EPROTO; return -1; }
@@ -313,7 +320,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
     for (uint32_t j = 0; j < used; ++j) {
       const uint32_t w = rk[j] / kWindowRanks, r = rk[j] % kWindowRanks;
       ent[slice_off[uint64_t(w) * kNumCodes + t] + fill[w]++] = uint16_t(r);
-      const uint32_t id = bm_id[uint64_t(w) * kNumCodes + t];         // (a slice belongs to one worker: no race)
+      const uint32_t id = with_bitmaps ? bm_id[uint64_t(w) * kNumCodes + t] : kNoBitmap;   // (a slice belongs to one worker: no race)
       if (id != kNoBitmap) bitmaps[size_t(id) * kBitmapWords + (r >> 5)] |= 1u << (r & 31);
     }
     std::vector<uint16_t> tmp;
@@ -415,11 +422,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
   ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz; ix.n_slots = n_slots;
   ix.built_from = host.generation();
   ix.n_bitmaps = n_bitmaps;
-  {
-    double sq = 0.0;
-    for (uint32_t t = 0; t < kNumCodes; ++t) sq += double(code_total[t]) * double(code_total[t]);
-    ix.mean_hit_slice = nnz ? sq / double(nnz) / double(n_win) : 0.0;
-  }
+  ix.mean_hit_slice = mean_hit_slice;
   while (ix.nib_windows + 1 < n_win && win_max_tri[ix.nib_windows] <= 15 && win_max_tri[ix.nib_windows + 1] <= 15)
     ix.nib_windows += 2;
   auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {   // v may be a temporary
@@ -434,7 +437,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out) {
       up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
       up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1) ||
       up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1) ||
-      up(&ix.d_bm_id, bm_id, 1) || up(&ix.d_bitmaps, bitmaps, 1)) {
+      (with_bitmaps && (up(&ix.d_bm_id, bm_id, 1) || up(&ix.d_bitmaps, bitmaps, 1)))) {
     const int e = errno;
     device_index_free(&ix);
     errno = e;

@@ -46,9 +46,10 @@
 
 // This file is compiled twice (csrc/Makefile): as it is -- the kernels that are timed, with no trace of
 // the request counters -- and through find_kernels_counted.hip with BLURRILY_COUNTED defined, into
-// namespace blurrily::counted: the same kernels keeping FindArgs::stats (blurrily_storage_set_stats).
+// namespace blurrily::counted: the same kernels keeping FindArgs::stats (blurrily_storage_set_stats) and, when
+// FindArgs::phase_clocks is set, wave 0's shader clocks per phase of the sweep (tools/phase_profile.py).
 // (Counting behind a run-time `if (A.stats)` cost the needle-major kernel 7 %: registers and branches
-// in its innermost loops, measured on one box, tools/ab_probe.py.)
+// in its innermost loops, measured on one box, tools/ab_probe.py.)  This is the file's only build switch.
 #ifdef BLURRILY_COUNTED
 #define STATS(A) ((A).stats)
 #define BLURRILY_KERNELS_BEGIN namespace counted {
@@ -66,58 +67,14 @@ namespace {
 
 constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 
-#ifndef BLURRILY_COOP
-#define BLURRILY_COOP 1                // 1: one wave per step publishes the units (sweep_coop); 0: every wave walks the table
-#endif
-#ifndef BLURRILY_NIBBLE
-#define BLURRILY_NIBBLE 1              // needles with <= 15 trigrams count in 4 bits, two windows per step
-#endif
-#ifndef BLURRILY_COOP_RANGED
-#define BLURRILY_COOP_RANGED 1         // latency mode sweeps its ranges with sweep_coop as well
-#endif
-#ifndef BLURRILY_NIB_PREFIX
-#define BLURRILY_NIB_PREFIX 1          // needles with > 15 trigrams also count the short-reference windows in 4 bits
-#endif
-#ifndef BLURRILY_RANK_SORT_MAX
-#define BLURRILY_RANK_SORT_MAX 256     // pools up to this size are compacted by rank counting, larger ones by a bitonic sort
-#endif
-#ifndef BLURRILY_COOP_ROTATE
-#define BLURRILY_COOP_ROTATE 1         // sweep_coop: the publishing turn rotates over the waves (0: always the last wave)
-#endif
-#ifndef BLURRILY_NEXT_BEFORE_BARRIER
-#define BLURRILY_NEXT_BEFORE_BARRIER 1 // sweep_coop: the step after the next is chosen before the count barrier, not after
-#endif
-#ifndef BLURRILY_ADDTID_CLEAR
-#define BLURRILY_ADDTID_CLEAR 0        // 1: the scan clears counters with ds_write_addtid_b32, a KiB per wave at a time
-                                       // (measured, same box: 391.2 vs 379.7 ms per 500 k needles -- 3 % SLOWER than the
-                                       // lane-wise ds_write_b128: the LDS store path is not what the step waits for)
-#endif
-#ifndef BLURRILY_SCAN_PREFILTER
-#define BLURRILY_SCAN_PREFILTER 1      // the scan tests a vector with one AND before the exact SWAR test
-#endif
-#ifndef BLURRILY_COOP_PUBLISH
-#ifndef BLURRILY_LANE_PREDICATE
-#define BLURRILY_LANE_PREDICATE 1       // sweep_coop: a unit's loaded lanes as a lane predicate, not as sentinels in idle lanes
-#endif
-#ifndef BLURRILY_WMT_IN_LDS
-#define BLURRILY_WMT_IN_LDS 1          // the per-window bound as bytes in LDS (find_kernel), read by the step-choosing wave
-#endif
-#ifndef BLURRILY_SERIAL_PRIO
-#define BLURRILY_SERIAL_PRIO 2           // wave priority in a workgroup's serial sections (between needles, compaction, cold start)
-#endif
-#define BLURRILY_COOP_PUBLISH 1        // sweep_coop: one wave per step chooses the next step and publishes it with the units
-#endif
-#ifndef BLURRILY_CLEAR_WRITE2
-#define BLURRILY_CLEAR_WRITE2 0        // 1: the scan clears a vector with ds_write2_b64 from one 64-bit zero -- 6 VALU per
-                                       // scanned vector instead of 10, yet 2.3 % SLOWER (356.5 vs 348.3 ms, same box)
-#endif
-#ifndef BLURRILY_HEAD_UNITS
-#define BLURRILY_HEAD_UNITS 4          // units of the next window in flight for needles with <= 64 trigrams
-#endif
+constexpr int      kFindThreads    = 1024; // find_kernel's workgroup: sixteen waves, two workgroups per CU (256 and 512 were
+                                           // measured slower in round 1 and are no longer built)
+constexpr uint32_t kRankSortMax    = 256;  // pools up to this size are compacted by rank counting, larger ones by a bitonic sort
+constexpr int      kSerialPrio     = 2;    // wave priority in a workgroup's serial sections (between needles, compaction, cold start)
 
-// Optional phase profile (make profile): wave 0's shader-clock time per phase of the sweep,
-// accumulated per workgroup into FindArgs::phase_clocks[blockIdx.x * 8 + phase].
-#ifdef BLURRILY_PHASE_PROFILE
+// Phase profile (counted build only): wave 0's shader-clock time per phase of the sweep,
+// accumulated per workgroup into FindArgs::phase_clocks[blockIdx.x * 16 + phase].
+#ifdef BLURRILY_COUNTED
 #define PHASE_DECL unsigned long long ph_last = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_units = 0, ph_lanes = 0
 // head units of wave 0 and their live lanes (lane utilisation of the LDS atomics)
 // per needle, in the kernel body: slot 10 setup (queue pop .. first sweep), 11 the sweeps, 12 final compaction and rows
@@ -563,10 +520,10 @@ __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uin
 // threshold.  Called by all threads of the workgroup.
 template <int NT>
 __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t cap, uint32_t keep) {
-  __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);            // barriers and LDS round trips, nothing to overlap inside the workgroup
+  __builtin_amdgcn_s_setprio(kSerialPrio);            // barriers and LDS round trips, nothing to overlap inside the workgroup
   const uint32_t tid = threadIdx.x;
   const uint32_t n = min(ctl->pool_n, cap);
-  if (BLURRILY_RANK_SORT_MAX && n <= BLURRILY_RANK_SORT_MAX) {
+  if (n <= kRankSortMax) {
     // Small pools (most of them): every key counts the keys below it -- the keys are distinct,
     // a rank being harvested once -- and the best `keep` go straight to their places: three
     // barriers instead of the bitonic network's dozens.
@@ -626,29 +583,6 @@ __device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint3
   return max(1u, uint32_t(thr) >= wbase ? matches_k : matches_k + 1);
 }
 
-// Clear the 1 KiB of LDS at byte offset `lds_off` (wave-uniform): four ds_write_addtid_b32 -- address =
-// M0 + offset + 4 * lane, no address VGPR -- at 2 cycles per 256 bytes on the LDS store path, against 13
-// cycles per KiB for the ds_write_b128 a lane-wise clear compiles to (MI355X_MICROARCH.md, LDS).
-[[maybe_unused]] __device__ __forceinline__ void lds_clear_1k(uint32_t lds_off) {
-  uint32_t z = 0, saved_m0;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-               "ds_write_addtid_b32 %2 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
-               "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %2 offset:768\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(saved_m0) : "s"(lds_off), "v"(z) : "memory");
-}
-[[maybe_unused]] __device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
-  return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
-      (const __attribute__((address_space(3))) void*)p));
-}
-
-// 16 bytes of LDS zeroed with one ds_write2_b64 whose two data operands are the same zero pair
-[[maybe_unused]] __device__ __forceinline__ void lds_zero16(void* p16) {
-  const uint32_t a = lds_offset_of(p16);
-  unsigned long long z = 0;
-  asm volatile("ds_write2_b64 %0, %1, %1 offset1:1" :: "v"(a), "v"(z) : "memory");
-}
-
 // ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
@@ -689,58 +623,27 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
     };
     // (Measured alternatives: a thread's vectors two at a time -- reads in flight together, one
     // zero quad -- 3.5% slower; read-and-clear in one ds_wrxchg_rtn_b64 per 8 bytes: +0.5%, noise.)
-#if BLURRILY_ADDTID_CLEAR
-    // A wave's 64 lanes read 1 KiB of contiguous counters per round; the wave then clears that KiB
-    // itself (LDS operations of one wave execute in order).
-    const uint32_t lds0 = lds_offset_of(cnt128);
-    for (uint32_t base = (tid & ~63u); base < nvec; base += NT) {       // wave-uniform
-      const uint32_t i = base + (tid & 63u);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (i < nvec) v = cnt128[i];
-      lds_clear_1k(__builtin_amdgcn_readfirstlane(lds0 + base * 16));
-      v = S::mask_pad(v, i);
-      if (S::any_hit(v, nq)) harvest(v, i);
-    }
-#else
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint4 v = cnt128[i];
-#if BLURRILY_CLEAR_WRITE2
-      // 16 bytes of zeros from ONE 64-bit zero (ds_write2_b64 takes the same register pair twice): a
-      // zero quad would be re-materialised every iteration (four v_mov) or, hoisted, spill under the
-      // 64-VGPR budget
-      lds_zero16(&cnt128[i]);
-#else
       // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held
       // in four VGPRs for the whole sweep and spilled to scratch under the 64-VGPR budget.
       uint32_t z = 0;
       asm volatile("" : "+v"(z));
       cnt128[i] = make_uint4(z, z, z, z);
-#endif
       v = S::mask_pad(v, i);
       // one SWAR test per vector: the top bit of a field is set iff its counter >= need
-#if BLURRILY_SCAN_PREFILTER
       if (S::maybe(v, nq) && S::any_hit(v, nq)) {
         __builtin_amdgcn_s_setprio(3);     // a wave that found something is the one the scan barrier will wait for
         harvest(v, i);
       }
-#else
-      if (S::any_hit(v, nq)) harvest(v, i);
-#endif
     }
-#endif
   } else {
     // nothing in this window can enter the pool any more: just clear the counters
-#if BLURRILY_ADDTID_CLEAR
-    const uint32_t lds0 = lds_offset_of(cnt128);
-    for (uint32_t base = (tid & ~63u); base < nvec; base += NT)
-      lds_clear_1k(__builtin_amdgcn_readfirstlane(lds0 + base * 16));
-#else
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint32_t z = 0;
       asm volatile("" : "+v"(z));
       cnt128[i] = make_uint4(z, z, z, z);
     }
-#endif
   }
   S::clear_unreached_pad(cnt128, nvec, tid);
   __builtin_amdgcn_s_setprio(0);
@@ -758,7 +661,7 @@ __device__ __forceinline__ uint32_t cold_start_need(const uint4* cnt128, uint32_
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t nvec = S::nvec(wlen);
   uint32_t lo = 1, hi = min(T, S::kMaxCount);            // answer in [lo, hi]; lo = 1 means "no restriction"
-  __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);
+  __builtin_amdgcn_s_setprio(kSerialPrio);
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (tid == 0) ctl->tally = 0;
@@ -909,26 +812,24 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
     }                                                                                            \
   } while (0)
 
-// Head of a window: the first KP (<= 4) units of this wave (c == b == 0: no such unit).
+// Head of a window: the first three units of this wave (c == b == 0: no such unit).
 // `more` = the wave owns further units; returns true if the window holds any posting.
-template <int kNW, int KP>
+template <int kNW>
 __device__ __forceinline__ bool head_units(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, bool two_slots,
                                            uint32_t wid, uint32_t lane, bool& more, uint32_t& c0, uint32_t& e0,
-                                           uint32_t& c1, uint32_t& e1, uint32_t& c2, uint32_t& e2, uint32_t& c3,
-                                           uint32_t& e3) {
-  uint32_t k = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0, x3 = 0, y3 = 0;
+                                           uint32_t& c1, uint32_t& e1, uint32_t& c2, uint32_t& e2) {
+  uint32_t k = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
 #define BLURRILY_KEEP_HEAD                                   \
   {                                                          \
     x0 = k == 0 ? c : x0; y0 = k == 0 ? sb : y0;             \
     x1 = k == 1 ? c : x1; y1 = k == 1 ? sb : y1;             \
     x2 = k == 2 ? c : x2; y2 = k == 2 ? sb : y2;             \
-    if (KP > 3) { x3 = k == 3 ? c : x3; y3 = k == 3 ? sb : y3; } \
   }
   BLURRILY_FOR_SLOT_UNITS(kNW, a0, b0, wid, lane, k, BLURRILY_KEEP_HEAD);
   if (two_slots) BLURRILY_FOR_SLOT_UNITS(kNW, a1, b1, wid, lane, k, BLURRILY_KEEP_HEAD);
 #undef BLURRILY_KEEP_HEAD
-  c0 = x0; e0 = y0; c1 = x1; e1 = y1; c2 = x2; e2 = y2; c3 = x3; e3 = y3;
-  more = k > uint32_t(KP);
+  c0 = x0; e0 = y0; c1 = x1; e1 = y1; c2 = x2; e2 = y2;
+  more = k > 3u;
   return (__ballot(b0 > a0) | __ballot(b1 > a1)) != 0;
 }
 
@@ -954,9 +855,9 @@ __device__ __forceinline__ void count_rest(const uint16_t* ent, uint32_t* cnt32,
 // registers and, while window w is scanned, already has its first three units of window w+1
 // in flight.  A window costs two barriers and, in steady state, no exposed global-memory
 // round trip.
-// SLOTS2: the needle may have more than 64 distinct trigrams (second table slot per lane);
-// KP: units of the next window kept in flight (3, or 4 when the second slot's registers are free).
-template <typename CT, int NT, bool SLOTS2, int KP>
+// Serves needles with 65..128 distinct trigrams (a second table slot per lane) and the wide-counter launches;
+// needles with <= 64 trigrams -- nearly all -- take sweep_coop below.
+template <typename CT, int NT>
 __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
                                 unsigned long long* pool, Control* ctl, const uint32_t w0, const uint32_t w1,
                                 const uint32_t ws) {
@@ -964,13 +865,13 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
   // class first (its best matches, so the threshold tightens early), the rest after.  A window
   // whose references cannot reach the threshold (win_max_tri) is skipped without being loaded.
   constexpr uint32_t kNW = NT / 64;
-  constexpr uint32_t kPre = KP;                                 // units loaded one window ahead
+  constexpr uint32_t kPre = 3;                                  // units loaded one window ahead
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t tc = nd.T;                                     // <= 128
   const uint32_t nwin = w1;                                     // windows [w0, w1) of the rank space
-  const bool two_slots = SLOTS2 && tc > 64;
+  const bool two_slots = tc > 64;
 
-  const bool own0 = lane < tc, own1 = SLOTS2 && lane + 64 < tc;
+  const bool own0 = lane < tc, own1 = lane + 64 < tc;
   const uint32_t code0 = own0 ? codes[lane] : 0u;
   const uint32_t code1 = own1 ? codes[lane + 64] : 0u;
   // slice tables of window w (ca*/cb*) and w+1 (na*/nb*), plain registers
@@ -981,22 +882,21 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     if ((w_) < nwin) {                                                           \
       const uint32_t* soff_ = A.slice_off + size_t(w_) * kNumCodes;              \
       if (own0) { A0 = soff_[code0]; B0 = soff_[code0 + 1]; }                    \
-      if (SLOTS2 && own1) { A1 = soff_[code1]; B1 = soff_[code1 + 1]; }          \
+      if (own1) { A1 = soff_[code1]; B1 = soff_[code1 + 1]; }                    \
     }                                                                            \
   } while (0)
 
   // head of a window: its first kPre units of this wave, loaded ahead of time
-  uint4 u0, u1, u2, u3 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
+  uint4 u0, u1, u2;
   bool head_any = false, head_more = false;                     // of the window the head belongs to
-  uint32_t hc0, hb0, hc1, hb1, hc2, hb2, hc3, hb3;
+  uint32_t hc0, hb0, hc1, hb1, hc2, hb2;
 #define BLURRILY_LOAD_HEAD(A0, B0, A1, B1)                                                          \
   do {                                                                                              \
-    head_any = head_units<kNW, KP>(A0, B0, A1, B1, two_slots, wid, lane, head_more, hc0, hb0, hc1,  \
-                                   hb1, hc2, hb2, hc3, hb3);                                        \
+    head_any = head_units<kNW>(A0, B0, A1, B1, two_slots, wid, lane, head_more, hc0, hb0, hc1,      \
+                               hb1, hc2, hb2);                                                      \
     u0 = load_group(A.ent, hc0, hb0);                                                               \
     u1 = load_group(A.ent, hc1, hb1);                                                               \
     u2 = load_group(A.ent, hc2, hb2);                                                               \
-    if (KP > 3) u3 = load_group(A.ent, hc3, hb3);                                                   \
   } while (0)
 
   const uint32_t n_visit = w1 - w0;
@@ -1020,14 +920,11 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     if (any) {
       // ---- count window w: its head was loaded one window ago ---------------------------
       PHASE_UNIT(u0); PHASE_UNIT(u1); PHASE_UNIT(u2);
-      if (KP > 3) PHASE_UNIT(u3);
       stat_unit(STATS(A), u0); stat_unit(STATS(A), u1); stat_unit(STATS(A), u2);
-      if (KP > 3) stat_unit(STATS(A), u3);
       if (STATS(A) && tid == 0) atomicAdd(&STATS(A)[kStatSteps], 1ull);
       bump8<CT>(cnt32, u0);
       bump8<CT>(cnt32, u1);
       bump8<CT>(cnt32, u2);
-      if (KP > 3) bump8<CT>(cnt32, u3);
       PHASE_MARK(1);                                            // head counted
       if (more) count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, kPre, STATS(A));
       PHASE_MARK(2);                                            // rest counted
@@ -1172,21 +1069,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       if (lane == 0) ring->n_units[s_] = total_;                                 \
     }                                                                            \
   } while (0)
-  // one published unit: the lane's 16-byte group of it, and the parity of its window
-#define BLURRILY_LOAD_UNIT(s_, k_, U, H)                                         \
-  do {                                                                           \
-    const uint2 d_ = ring->desc[s_][k_];                                         \
-    const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                    \
-    const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                    \
-    H = x_ & 1u;                                                                 \
-    U = load_group(A.ent, (x_ & ~7u) + lane * 8, y_);                            \
-    if (STATS(A)) st_ent += min(512u, y_ - (x_ & ~7u));                           \
-  } while (0)
   // the units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
   // atomics run while the next unit's load is in flight
-#if BLURRILY_LANE_PREDICATE
-  /* which lanes loaded a group travels as a lane predicate (an SGPR pair) beside the unit in flight: no         \
-     sentinels to fill idle lanes with, no liveness test before the atomics */                                  \
+  // (which lanes loaded a group travels as a lane predicate -- an SGPR pair -- beside the unit in flight: no
+  // sentinels to fill idle lanes with, no liveness test before the atomics)
 #define BLURRILY_COUNT_UNITS(s_, n_)                                             \
   do {                                                                           \
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
@@ -1206,20 +1092,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     }                                                                            \
     if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);                 \
   } while (0)
-#else
-#define BLURRILY_COUNT_UNITS(s_, n_)                                             \
-  do {                                                                           \
-    uint4 pend_ = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);            \
-    uint32_t pend_h_ = 0;                                                        \
-    for (uint32_t k_ = wid; k_ < (n_); k_ += kNW) {                              \
-      uint4 v_; uint32_t vh_;                                                    \
-      BLURRILY_LOAD_UNIT(s_, k_, v_, vh_);                                       \
-      bump_unit<CT>(cnt32, pend_, pend_h_);                                      \
-      pend_ = v_; pend_h_ = vh_;                                                 \
-    }                                                                            \
-    bump_unit<CT>(cnt32, pend_, pend_h_);                                        \
-  } while (0)
-#endif
   // more units than the ring holds: every wave walks the table of step p_ itself
 #define BLURRILY_COUNT_WALK(p_)                                                  \
   do {                                                                           \
@@ -1233,16 +1105,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
                               { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); \
                                 if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
   } while (0)
-#if BLURRILY_COOP_ROTATE
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
-#else
-#define BLURRILY_PRODUCER(e_) (kNW - 1)                        /* units go round robin: the last wave has the fewest */
-#endif
 
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
   uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0;    // request counters (FindArgs::stats), wave-uniform
-#if BLURRILY_COOP_PUBLISH
   // Which step comes next is decided by ONE wave per step -- the one that then fetches that step's table --
   // and travels through LDS with the units: `step[slot]` beside `n_units[slot]`, the visit index chosen last in
   // `visit[]`.  The other fifteen waves read two words per step instead of each running the window-bound
@@ -1320,70 +1187,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       }
     }
   }
-#else
-  uint32_t i_cur = 0, i_next, i_next2;
-  // prologue: one wave publishes the first step, everyone agrees on the second
-  if (wid == BLURRILY_PRODUCER(0u)) {
-    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
-    BLURRILY_PRODUCE(0u, ta, tb, ta1, tb1);
-  }
-  __syncthreads();
-  BLURRILY_NEXT_VISIT(1u, i_next);
-  if (wid == BLURRILY_PRODUCER(1u)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next), ta, tb, ta1, tb1);
-
-  for (uint32_t e = 0; i_cur < n_visit; ++e) {
-    const uint32_t s = e & 1;
-    const uint32_t p = BLURRILY_STEP_AT(i_cur);
-    const uint32_t wbase = p * kWPS * kWindowRanks;
-    const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-    const uint32_t n_units = ring->n_units[s];
-    ++st_steps;
-    PHASE_MARK(0);                                              // loop overhead
-    // ---- count step p --------------------------------------------------------------------
-    if (n_units == kRingOverflow) {
-      BLURRILY_COUNT_WALK(p);
-    } else {
-      BLURRILY_COUNT_UNITS(s, n_units);
-    }
-    PHASE_MARK(2);                                              // units counted
-    // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
-    if (wid == BLURRILY_PRODUCER(e + 1)) {
-      if (i_next < n_visit) BLURRILY_PRODUCE(s ^ 1u, ta, tb, ta1, tb1);
-      else if (lane == 0) ring->n_units[s ^ 1u] = 0;
-    }
-    PHASE_MARK(7);                                              // (producer turn) next step's units published
-#if BLURRILY_NEXT_BEFORE_BARRIER
-    // ---- decide the step after the next BEFORE the barrier: the threshold only changes behind select's
-    // barriers, so the answer is the same, and the window-bound load and the table fetch travel under
-    // the wait for the slowest wave instead of standing between the barrier and the scan ----------
-    BLURRILY_NEXT_VISIT(i_next + 1, i_next2);
-    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb, ta1, tb1);
-#endif
-    __syncthreads();                                            // counts and next descriptors visible
-    PHASE_MARK(3);                                              // barrier after count
-#if !BLURRILY_NEXT_BEFORE_BARRIER
-    // ---- decide the step after the next; its table travels during the scan -------------------
-    BLURRILY_NEXT_VISIT(i_next + 1, i_next2);                   // uniform: thr only changes behind select's barriers
-    if (wid == BLURRILY_PRODUCER(e + 2)) BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(i_next2), ta, tb, ta1, tb1);
-#endif
-    PHASE_MARK(4);                                              // step after the next chosen
-    if (n_units) {
-      for (;;) {
-        scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
-        PHASE_MARK(5);                                          // scan
-        __syncthreads();                                        // counters are zero again
-        PHASE_MARK(6);                                          // barrier after scan
-        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
-        ++st_redo;
-        if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
-        else BLURRILY_COUNT_UNITS(s, n_units);
-        __syncthreads();
-      }
-    }
-    i_cur = i_next;
-    i_next = i_next2;
-  }
-#endif
   PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
     atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
@@ -1397,7 +1200,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #undef BLURRILY_PRODUCER
 #undef BLURRILY_COUNT_WALK
 #undef BLURRILY_COUNT_UNITS
-#undef BLURRILY_LOAD_UNIT
 #undef BLURRILY_PRODUCE
 #undef BLURRILY_FETCH_TABLE
 #undef BLURRILY_NEXT_VISIT
@@ -1436,7 +1238,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
   // lives in the slice table of the long-needle sweep, which the SHORT instantiations never use; clamped to 255,
   // exact for the <= 64 trigrams of a needle that gets here.
   const uint8_t* wmt = nullptr;
-  if constexpr (SHORT && BLURRILY_WMT_IN_LDS) {
+  if constexpr (SHORT) {
     if (A.n_windows <= 2 * kCodeChunk * 4) {
       uint8_t* w8 = reinterpret_cast<uint8_t*>(s_tab);
       for (uint32_t i = tid; i < A.n_windows; i += NT) w8[i] = uint8_t(min(A.win_max_tri[i], 255u));
@@ -1450,7 +1252,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
   PHASE_NEEDLE_DECL;
   for (;;) {
-    __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);        // between two needles: one chain of round trips
+    __builtin_amdgcn_s_setprio(kSerialPrio);        // between two needles: one chain of round trips
     if (tid == 0) ctl->q = atomicAdd(A.queue, 1u);
     __syncthreads();
     const uint32_t slot = ctl->q;
@@ -1503,23 +1305,20 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 #define BLURRILY_SWEEP(a_, b_, start_)                                                                  \
   do {                                                                                                  \
     const uint32_t sa = (a_), sb = (b_), st = (start_);                                                 \
-    if constexpr (SHORT && (!RANGED || BLURRILY_COOP_RANGED) && BLURRILY_COOP) {                        \
+    if constexpr (SHORT) {                                                                              \
       /* 4-bit counters, two windows per step: every window for a needle with <= 15 trigrams, and for   \
          ANY needle the leading windows whose references have <= 15 trigrams (ranks follow weight, i.e. \
          length: about half the windows at Geonames scale) -- a counter there cannot exceed 15 whatever \
          the needle.  The byte-counter part goes first: it holds the needle's own length class. */      \
-      const uint32_t nib_end = !BLURRILY_NIBBLE ? sa : nd.T <= 15 ? sb                                  \
-                               : BLURRILY_NIB_PREFIX ? min(sb, max(sa, A.nib_windows)) : sa;            \
+      const uint32_t nib_end = nd.T <= 15 ? sb : min(sb, max(sa, A.nib_windows));                       \
       if (nib_end < sb)                                                                                 \
         sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, nib_end, sb, max(st, nib_end));        \
       if (sa < nib_end)                                                                                 \
         sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, sa, nib_end, min(st, nib_end - 1));   \
-    } else if constexpr (SHORT) {                                                                       \
-      sweep_pipelined<CT, NT, false, BLURRILY_HEAD_UNITS>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);  \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
-      sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);                     \
+      sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);                              \
     } else {                                                                                            \
-      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT, true, 3>(A, nd, codes, cnt32, pool, ctl, sa, sb, st); \
+      if (nd.T <= kCodeChunk) sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);    \
       else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, sa, sb);     \
     }                                                                                                   \
   } while (0)
@@ -1542,7 +1341,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
     compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
-    __builtin_amdgcn_s_setprio(BLURRILY_SERIAL_PRIO);
+    __builtin_amdgcn_s_setprio(kSerialPrio);
     const uint32_t nres = ctl->pool_n;
     if (RANGED) {
       // latency mode: leave this range's best keys for merge_parts_kernel
@@ -1722,13 +1521,11 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
 // One task = (needle, window), run by a workgroup of 4 waves with 32 KiB of counters -- four
 // workgroups per CU: 4-bit counters for the whole window when a cold count cannot exceed 15 (nearly
 // always: the cold slices are few), else byte counters over the two halves of the window in turn.
-#ifndef BLURRILY_WS_THREADS
-#define BLURRILY_WS_THREADS 256        // (512 -- eight waves per task and SIMD, 64 VGPRs, 100 B of scratch -- measured:
-#endif                                 //  configs[2] 322 -> 346 ms per 300 k needles, configs[4] 82.3 -> 85.6 ms)
-constexpr int      kWsNT    = BLURRILY_WS_THREADS;
+constexpr int      kWsNT    = 256;             // (512 -- eight waves per task and SIMD, 64 VGPRs, 100 B of scratch -- measured:
+                                               //  configs[2] 322 -> 346 ms per 300 k needles, configs[4] 82.3 -> 85.6 ms)
 constexpr uint32_t kWsNW    = kWsNT / 64;
 constexpr uint32_t kWsChunk = 256;             // most needles per queue pop (the task arrays in LDS)
-constexpr uint32_t kWsAhead = kWsNT >= 512 ? 2 : 4;   // units a wave loads before it counts the first of them
+constexpr uint32_t kWsAhead = 4;               // units a wave loads before it counts the first of them
 constexpr uint32_t kWsCand  = 512;             // candidate list (rank | cold << 16): two per thread
 constexpr uint32_t kWsPool  = 256;             // candidate pool, >= 2 * kWsMaxKeep
 constexpr uint32_t kWsCntWords = kWindowSize / 8;   // 8192 words = 32 KiB: 65 536 nibbles or 32 768 bytes
@@ -2447,35 +2244,18 @@ int launch_merge_rows(const trigram_match_t* a_rows, const uint32_t* a_counts, c
   return 0;
 }
 
-int find_threads() {
-  static int nt = 0;
-  if (!nt) {
-    const char* e = std::getenv("BLURRILY_FIND_THREADS");
-    nt = e ? std::atoi(e) : 1024;
-    if (nt != 256 && nt != 512 && nt != 1024) nt = 1024;
-  }
-  return nt;
-}
+int find_threads() { return kFindThreads; }
 
 uint32_t find_wgs_per_cu() {
   const uint32_t by_lds = uint32_t((160 * 1024) / find_lds_bytes(1, 1024));
-  const uint32_t by_waves = 32u / uint32_t(find_threads() / 64);
-  uint32_t n = std::max(1u, std::min(by_lds, by_waves));
-  if (const char* e = std::getenv("BLURRILY_FIND_WGS_PER_CU")) n = std::max(1, std::min<int>(int(n), std::atoi(e)));   // experiments
-  return n;
+  const uint32_t by_waves = 32u / uint32_t(kFindThreads / 64);
+  return std::max(1u, std::min(by_lds, by_waves));
 }
 
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
   if (grid == 0) return 0;
-  const int nt = find_threads();
-  if (!long_needles) {
-    if (nt == 256) return launch_find_t<uint8_t, 256>(a, grid, stream);
-    if (nt == 512) return launch_find_t<uint8_t, 512>(a, grid, stream);
-    return launch_find_t<uint8_t, 1024>(a, grid, stream);
-  }
-  if (nt == 256) return launch_find_t<uint16_t, 256>(a, grid, stream);
-  if (nt == 512) return launch_find_t<uint16_t, 512>(a, grid, stream);
-  return launch_find_t<uint16_t, 1024>(a, grid, stream);
+  if (!long_needles) return launch_find_t<uint8_t, kFindThreads>(a, grid, stream);
+  return launch_find_t<uint16_t, kFindThreads>(a, grid, stream);
 }
 
 BLURRILY_KERNELS_END

@@ -2,6 +2,7 @@
 #include "host_index.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cerrno>
 #include <climits>
@@ -17,14 +18,18 @@
 
 namespace blurrily {
 
+namespace {
+std::atomic<unsigned> g_host_threads{0};
+std::atomic<bool>     g_build_trace{false};
+}  // namespace
+
+void set_host_threads(unsigned n) { g_host_threads.store(std::min(n, 256u)); }
 unsigned host_threads() {
-  unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-  if (const char* e = std::getenv("BLURRILY_HOST_THREADS")) {
-    const long v = std::atol(e);
-    if (v >= 1) n = unsigned(std::min<long>(v, 256));
-  }
-  return n;
+  const unsigned n = g_host_threads.load();
+  return n ? n : std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
 }
+void set_build_trace(bool on) { g_build_trace.store(on); }
+bool build_trace() { return g_build_trace.load(); }
 
 namespace {
 
@@ -68,15 +73,14 @@ void RefSet::clear() {
   key_ = nullptr; tag_ = nullptr; cap_ = live_ = filled_ = 0;
 }
 
-void RefSet::rehash(uint64_t want) {
+bool RefSet::rehash(uint64_t want) {
   uint64_t cap = 1024;
   while (cap < want * 2) cap <<= 1;
   uint32_t* nk = static_cast<uint32_t*>(std::malloc(cap * sizeof(uint32_t)));
   uint8_t*  nt = static_cast<uint8_t*>(std::calloc(cap, 1));
-  if (!nk || !nt) {                                               // out of memory: keep the table as it is (it is
-    std::free(nk); std::free(nt);                                 // grown long before it is full, so adds still fit)
-    if (cap_) return;
-    std::fprintf(stderr, "blurrily_hip: out of memory\n"); std::abort();
+  if (!nk || !nt) {                                               // out of memory: the table stays as it is;
+    std::free(nk); std::free(nt);                                 // ensure_room() tells the caller when it is too full
+    return false;
   }
   uint64_t live = 0;
   for (uint64_t i = 0; i < cap_; ++i) {
@@ -87,9 +91,16 @@ void RefSet::rehash(uint64_t want) {
   }
   std::free(key_); std::free(tag_);
   key_ = nk; tag_ = nt; cap_ = cap; live_ = filled_ = live;
+  return true;
 }
 
-void RefSet::reserve(uint64_t n) { if (n * 2 > cap_) rehash(n); }
+void RefSet::reserve(uint64_t n) { if (n * 2 > cap_) (void)rehash(n); }
+
+bool RefSet::ensure_room() {
+  if ((filled_ + 1) * 2 <= cap_) return true;
+  if (rehash(std::max<uint64_t>(live_ + 1, 512))) return true;   // (also drops the tombstones of removed references)
+  return cap_ != 0 && (filled_ + 1) * 8 <= cap_ * 7;
+}
 
 bool RefSet::test(uint32_t ref) const {
   if (!cap_) return false;
@@ -102,7 +113,6 @@ bool RefSet::test(uint32_t ref) const {
 }
 
 void RefSet::add(uint32_t ref) {
-  if ((filled_ + 1) * 2 > cap_) rehash(std::max<uint64_t>(live_ + 1, 512));
   uint64_t h = mix(ref) & (cap_ - 1);
   while (tag_[h] == 1) h = (h + 1) & (cap_ - 1);
   if (tag_[h] == 0) ++filled_;
@@ -141,7 +151,10 @@ void HostIndex::ensure_refset() {
   refs_.reserve(std::max<uint64_t>(lead, total_refs_));
   auto add_bucket = [&](const Bucket& bk) {
     for (uint32_t j = 0; j < bk.used; ++j)
-      if (!refs_.test(bk.e[j].ref)) refs_.add(bk.e[j].ref);
+      if (!refs_.test(bk.e[j].ref)) {
+        if (!refs_.ensure_room()) { std::fprintf(stderr, "blurrily_hip: out of memory (reference set)\n"); std::abort(); }
+        refs_.add(bk.e[j].ref);
+      }
   };
   if (lead == total_refs_) {
     for (uint32_t s = 0; s < uint32_t(kBase) - 1; ++s) add_bucket(b_[s * kBase * kBase]);
@@ -155,6 +168,7 @@ void HostIndex::ensure_refset() {
 int HostIndex::put(const char* needle, size_t len, uint32_t ref, uint32_t weight) {
   ensure_refset();
   if (refs_.test(ref)) return 0;                                  // storage.c:408
+  if (!refs_.ensure_room()) { errno = ENOMEM; return -1; }        // (before anything is touched)
   if (weight == 0) weight = uint32_t(len);                        // storage.c:409
 
   uint16_t  small[256];
@@ -163,8 +177,8 @@ int HostIndex::put(const char* needle, size_t len, uint32_t ref, uint32_t weight
   if (!codes) { errno = ENOMEM; return -1; }
   const int n = tokenise(needle, len, codes);                     // storage.c:412
 
-  // Room first, entries after: an allocation that fails leaves the map as it was (the reference's
-  // smalloc asserts instead, storage.c:93-98).  A bucket grows exactly when the reference's would --
+  // Room first, entries after: an allocation that fails adds no entry (the reference's smalloc asserts
+  // instead, storage.c:93-98; buckets grown before the failure keep their new capacity).  A bucket grows exactly when the reference's would --
   // when it is full and about to take an entry -- so files stay byte-identical.
   for (int k = 0; k < n; ++k) {                                   // storage.c:424-458
     Bucket& bk = b_[codes[k]];
@@ -200,7 +214,7 @@ int HostIndex::put(const char* needle, size_t len, uint32_t ref, uint32_t weight
 long HostIndex::put_many(const char* packed, const uint64_t* offsets, const uint32_t* refs,
                          const uint32_t* weights, size_t n) {
   if (n == 0) return 0;
-  const bool trace = std::getenv("BLURRILY_BUILD_TRACE") != nullptr;
+  const bool trace = build_trace();
   auto t_last = std::chrono::steady_clock::now();
   auto stage = [&](const char* what) {
     if (!trace) return;
@@ -216,7 +230,13 @@ long HostIndex::put_many(const char* packed, const uint64_t* offsets, const uint
   size_t accepted = 0;
   for (size_t i = 0; i < n; ++i) {
     take[i] = !refs_.test(refs[i]);
-    if (take[i]) { refs_.add(refs[i]); ++accepted; }
+    if (!take[i]) continue;
+    if (!refs_.ensure_room()) {                                   // out of memory: nothing of this batch is stored
+      for (size_t j = 0; j < i; ++j) if (take[j]) refs_.remove(refs[j]);
+      errno = ENOMEM;
+      return -1;
+    }
+    refs_.add(refs[i]); ++accepted;
   }
   if (!accepted) return 0;
   stage("reference set");

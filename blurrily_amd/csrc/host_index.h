@@ -42,21 +42,29 @@ class RefSet {
  public:
   ~RefSet();
   bool test(uint32_t ref) const;
-  void add(uint32_t ref);      // caller guarantees !test(ref)
+  // Room for one more reference: grows the table when it is half full.  false = growth failed (out of
+  // memory) AND the table is 7/8 full -- one more add could leave no empty slot for test() to stop at.
+  bool ensure_room();
+  void add(uint32_t ref);      // caller guarantees !test(ref) and a successful ensure_room()
   void remove(uint32_t ref);
   void clear();
   void reserve(uint64_t n);
   uint64_t size() const { return live_; }
  private:
-  void rehash(uint64_t want);
+  bool rehash(uint64_t want);
   uint32_t* key_ = nullptr;
   uint8_t*  tag_ = nullptr;    // 0 empty, 1 full, 2 tombstone
   uint64_t  cap_ = 0, live_ = 0, filled_ = 0;
 };
 
-// Host threads for bulk work (put_many, the device-image transform): the hardware threads, at most
-// 64, or BLURRILY_HOST_THREADS when set (several ranks on one host share its cores).
+// Process-wide options (blurrily_storage_set_option with a NULL map).
+//   host_threads  threads for bulk work (put_many, the device-image transform); 0 = the hardware threads,
+//                 at most 64 (several ranks on one host share its cores: bench.py sets cores / world)
+//   build_trace   wall time of every stage of put_many / the device-image build on stderr
+void     set_host_threads(unsigned n);
 unsigned host_threads();
+void     set_build_trace(bool on);
+bool     build_trace();
 
 class HostIndex {
  public:

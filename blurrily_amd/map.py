@@ -215,6 +215,19 @@ class RawMap:
         self._check_open()
         self._lib.blurrily_storage_set_stats(self._h, 1 if enabled else 0)
 
+    def set_option(self, key, value):
+        """A tunable of this map (include/blurrily_storage.h: blurrily_storage_set_option)."""
+        self._check_open()
+        if self._lib.blurrily_storage_set_option(self._h, key.encode(), int(value)) < 0:
+            _raise_errno()
+
+    def get_option(self, key):
+        self._check_open()
+        out = C.c_longlong(0)
+        if self._lib.blurrily_storage_get_option(self._h, key.encode(), C.byref(out)) < 0:
+            _raise_errno()
+        return int(out.value)
+
     def find_stats(self):
         """Counters of the last find call made while set_stats(True): a dict by STAT_NAMES."""
         self._check_open()
@@ -227,6 +240,12 @@ class RawMap:
     def handle(self):
         self._check_open()
         return self._h
+
+
+def set_process_option(key, value):
+    """A process-wide tunable ("host_threads", "build_trace"; include/blurrily_storage.h)."""
+    if _native.lib().blurrily_storage_set_option(None, key.encode(), int(value)) < 0:
+        _raise_errno()
 
 
 def _as_bytes(s):

@@ -50,7 +50,13 @@ class Server:
         self._stopping = asyncio.Event()
         for sig in (signal.SIGINT, signal.SIGTERM):
             loop.add_signal_handler(sig, self._stopping.set)
-        loop.add_signal_handler(signal.SIGUSR1, lambda: asyncio.ensure_future(self._save()))
+        usr1_saves = set()                                           # (referenced until done: not collected mid-save)
+
+        def on_usr1():                                               # server.rb:26
+            task = asyncio.ensure_future(self._logged_save("USR1"))
+            usr1_saves.add(task)
+            task.add_done_callback(usr1_saves.discard)
+        loop.add_signal_handler(signal.SIGUSR1, on_usr1)
         self._server = await asyncio.start_server(self._handle, self._host, self._port)
         self.port = self._server.sockets[0].getsockname()[1]
         dispatcher = asyncio.ensure_future(self._dispatch())
@@ -64,6 +70,8 @@ class Server:
             await self._server.wait_closed()
             saver.cancel()
             dispatcher.cancel()
+            if usr1_saves:                                           # a save asked for by signal finishes first
+                await asyncio.gather(*usr1_saves, return_exceptions=True)
             # shutdown hook (server.rb:25): queued behind the batch in flight on the one worker
             # thread, so it sees every mutation that was acknowledged
             try:
@@ -82,15 +90,19 @@ class Server:
         release the GIL, so a save on the event-loop thread would race the worker)."""
         await asyncio.get_running_loop().run_in_executor(self._gpu, self._map_group.save)
 
+    async def _logged_save(self, what):
+        """A save whose failure (a full disk ...) is reported, not left to 'exception was never retrieved'."""
+        try:
+            await self._save()
+        except asyncio.CancelledError:
+            raise
+        except Exception as e:
+            print(f"blurrily: {what} save failed: {e}", flush=True)
+
     async def _periodic_save(self):                                  # server.rb:23-24
         while True:
             await asyncio.sleep(self._save_interval)
-            try:
-                await self._save()
-            except asyncio.CancelledError:
-                raise
-            except Exception as e:                                   # one failed save must not end the saver
-                print(f"blurrily: periodic save failed: {e}", flush=True)
+            await self._logged_save("periodic")                      # one failed save must not end the saver
 
     # ---- one connection ------------------------------------------------------------------------
     async def _handle(self, reader, writer):

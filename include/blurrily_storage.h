@@ -70,8 +70,9 @@ int blurrily_storage_save(trigram_map haystack, const char* path);
 
 /* storage.h:70 / storage.c:398-473.  Returns the number of trigrams added,
  * 0 if `reference` is already present.  weight == 0 -> strlen(needle).
- * Out of memory: -1 with errno ENOMEM and the map unchanged (the reference
- * asserts in smalloc, storage.c:93-98). */
+ * Out of memory: -1 with errno ENOMEM and no entry added (the reference
+ * asserts in smalloc, storage.c:93-98; a bucket grown before the failing
+ * allocation keeps its new capacity, which a later save writes out). */
 int blurrily_storage_put(trigram_map haystack, const char* needle,
                          uint32_t reference, uint32_t weight);
 
@@ -176,6 +177,22 @@ void blurrily_storage_set_timing(trigram_map haystack, int enabled);
  * Collecting costs a few scalar instructions per wave-load; leave it off when timing. */
 void blurrily_storage_set_stats(trigram_map haystack, int enabled);
 int  blurrily_storage_find_stats(trigram_map haystack, uint64_t* out8);
+
+/* Tunables (no reference counterpart; nothing on the find path reads the environment).
+ * Per map -- read by the map's next find; calls on one map are serial, as in the reference:
+ *   "wsweep"          1 (default) / 0: whether the window-major sweep may be taken at all
+ *   "ws_min_windows"  (8)     fewest windows of an image it is taken on
+ *   "ws_min_slice"    (3000)  least mean postings a needle trigram finds per window (measured gate)
+ *   "ws_min_needles"  (16384) smallest batch it is taken for
+ *   "ws_cmin"         (3)     counted matches a left-out slice must leave
+ *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing
+ *                             it rebuilds the device image at the next find
+ * Process-wide -- `haystack` NULL:
+ *   "host_threads"    (0 = hardware threads, at most 64) threads of put_many and of the device-image build
+ *   "build_trace"     (0) wall time of the build stages on stderr
+ * set: 0, or -1 with errno EINVAL (unknown key, value out of range).  get: the value in effect. */
+int blurrily_storage_set_option(trigram_map haystack, const char* key, long long value);
+int blurrily_storage_get_option(trigram_map haystack, const char* key, long long* value);
 
 #ifdef __cplusplus
 }

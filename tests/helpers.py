@@ -179,6 +179,23 @@ class Reference:
         return list(out[:n])
 
 
+def block_digests(rows, counts, block):
+    """SHA-256 per block of `block` consecutive needles: for each needle its count (u32), then its
+    first `count` rows (u32 reference, matches, weight), little endian.  rows: uint32[n, limit, 3]."""
+    import hashlib
+    rows = np.ascontiguousarray(rows, dtype="<u4")
+    counts = np.ascontiguousarray(counts, dtype="<u4")
+    out = []
+    for lo in range(0, len(counts), block):
+        h = hashlib.sha256()
+        for q in range(lo, min(len(counts), lo + block)):
+            c = int(counts[q])
+            h.update(counts[q:q + 1].tobytes())
+            h.update(rows[q, :c].tobytes())
+        out.append(h.hexdigest())
+    return out
+
+
 def build_pair(strings, refs=None, weights=None):
     """The same haystack in the product (RawMap) and in the oracle."""
     from blurrily_amd import RawMap

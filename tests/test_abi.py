@@ -60,3 +60,42 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_the_library_never_reads_the_environment():
+    """Tunables go through blurrily_storage_set_option: the library does not even import getenv, so nothing a
+    find reaches can depend on the environment (or race a setenv of the host program)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _native.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True)
+    assert not re.search(r"\b(secure_)?getenv\b", out.stdout)
+    # ... and the kernel source carries one build switch (the counted build), no experiment switches
+    src = open(os.path.join(ROOT, "blurrily_amd", "csrc", "find_kernels.hip")).read()
+    switches = set(re.findall(r"^#\s*if(?:n?def)?\s+!?\s*(?:defined\s*\(\s*)?(\w+)", src, flags=re.M))
+    assert switches == {"BLURRILY_COUNTED"}, switches
+
+
+def test_options_set_and_get():
+    from blurrily_amd import RawMap
+    from blurrily_amd.map import set_process_option
+    m = RawMap()
+    defaults = {"wsweep": 1, "ws_cmin": 3, "ws_min_windows": 8, "ws_min_needles": 16384, "dense_min": 1024}
+    for k, v in defaults.items():
+        assert m.get_option(k) == v, k
+    m.set_option("ws_cmin", 2)
+    m.set_option("wsweep", 0)
+    assert m.get_option("ws_cmin") == 2 and m.get_option("wsweep") == 0
+    other = RawMap()
+    assert other.get_option("ws_cmin") == 3                     # per map
+    for key, value in (("no_such_option", 1), ("ws_cmin", 0), ("dense_min", 1), ("wsweep", 7)):
+        with pytest.raises(OSError) as e:
+            m.set_option(key, value)
+        assert e.value.errno == errno.EINVAL
+    lib = _native.lib()
+    out = ctypes.c_longlong(-1)
+    set_process_option("host_threads", 3)
+    assert lib.blurrily_storage_get_option(None, b"host_threads", ctypes.byref(out)) == 0 and out.value == 3
+    set_process_option("host_threads", 0)                       # back to the hardware threads
+    assert lib.blurrily_storage_get_option(None, b"host_threads", ctypes.byref(out)) == 0 and out.value >= 1
+    with pytest.raises(OSError):
+        set_process_option("ws_cmin", 2)                        # a per-map key is not a process option
+    m.close(); other.close()

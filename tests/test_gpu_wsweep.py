@@ -2,10 +2,10 @@
 count and consulted through bitmaps, one launch per window, needle states in global memory) against
 the oracle, bit-exact, and against the needle-major sweep it replaces for large batches.
 
-The path is taken for batches of >= 16 384 needles (BLURRILY_WS_MIN_NEEDLES) over >= 8 windows
-(BLURRILY_WS_MIN_WINDOWS) with limit <= 128 whose slices are big (BLURRILY_WS_MIN_SLICE: the path
-pays a fixed price per (needle, window)); the tests lower those bounds through the environment
-(read at every find call) to reach it with haystacks the oracle checks in seconds."""
+The path is taken for batches of >= 16 384 needles (option ws_min_needles) over >= 8 windows
+(ws_min_windows) with limit <= 128 whose slices are big (ws_min_slice: the path pays a fixed price per
+(needle, window)); the tests lower those bounds per map through blurrily_storage_set_option to reach it
+with haystacks the oracle checks in seconds."""
 import os
 
 import numpy as np
@@ -19,22 +19,12 @@ from helpers import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def ws_env():
-    keys = ("BLURRILY_WSWEEP", "BLURRILY_WS_CMIN", "BLURRILY_WS_MIN_WINDOWS", "BLURRILY_WS_MIN_NEEDLES",
-            "BLURRILY_WS_MIN_SLICE")
-    saved = {k: os.environ.get(k) for k in keys}
-
-    def set_(**kw):
-        kw.setdefault("WS_MIN_SLICE", 0)                       # whatever the haystack's slice sizes
-        for k, v in kw.items():
-            os.environ["BLURRILY_" + k] = str(v)
-    yield set_
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+def _ws(m, **kw):
+    """Lower the sweep's bounds on map `m` (blurrily_storage_set_option) so that it is reached with haystacks the
+    oracle checks in seconds."""
+    kw.setdefault("ws_min_slice", 0)                           # whatever the haystack's slice sizes
+    for k, v in kw.items():
+        m.set_option(k, v)
 
 
 def _pair(hay, off):
@@ -80,49 +70,49 @@ def _mixed_needles(hay, off, n_q, seed):
 
 
 @pytest.mark.parametrize("limit,cmin", [(10, 2), (10, 1), (10, 3), (100, 2), (128, 2), (1, 2), (3, 2)])
-def test_geonames_medium_all_rows_vs_oracle(ws_env, limit, cmin):
-    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000, WS_CMIN=cmin)
+def test_geonames_medium_all_rows_vs_oracle(limit, cmin):
     hay, off = W.geonames(600000, 80000, 41)                   # 10 windows
     m, o = _pair(hay, off)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000, ws_cmin=cmin)
     packed, offs = _mixed_needles(hay, off, 6000, 42)
     _check_all(m, o, packed, offs, limit)
 
 
-def test_window_major_equals_needle_major(ws_env):
-    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+def test_window_major_equals_needle_major():
     hay, off = W.geonames(900000, 120000, 43)
     m, _ = _pair(hay, off)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000)
     packed, offs = _mixed_needles(hay, off, 30000, 44)
     a_rows, a_counts = m.find_batch_packed(packed, offs, 10)
-    ws_env(WSWEEP=0)
+    m.set_option("wsweep", 0)
     b_rows, b_counts = m.find_batch_packed(packed, offs, 10)
     assert np.array_equal(a_counts, b_counts)
     live = np.arange(10)[None, :] < a_counts[:, None].astype(np.int64)
     assert np.array_equal(np.where(live[:, :, None], a_rows, 0), np.where(live[:, :, None], b_rows, 0))
 
 
-def test_skewed_ties_and_limit_100(ws_env):
+def test_skewed_ties_and_limit_100():
     """Massive (matches, weight) ties: floods of equally good candidates, pool overflows, re-sweeps."""
-    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
     hay, off = W.skewed(600000, 45)
     m, o = _pair(hay, off)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000)
     q, qo = W.queries(hay, off, 2500, 46)
     _check_all(m, o, q, qo, 100)
     _check_all(m, o, q, qo, 10)
 
 
-def test_words_many_windows(ws_env):
-    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+def test_words_many_windows():
     hay, off = W.words(400000, 47)                             # 7 windows of single words
     m, o = _pair(hay, off)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000)
     q, qo = W.queries(hay, off, 8000, 48)
     _check_all(m, o, q, qo, 10)
 
 
-def test_tombstones_and_pending_puts_under_the_window_major_sweep(ws_env):
-    ws_env(WS_MIN_WINDOWS=4, WS_MIN_NEEDLES=1000)
+def test_tombstones_and_pending_puts_under_the_window_major_sweep():
     hay, off = W.geonames(500000, 60000, 49)
     m, o = _pair(hay, off)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000)
     q, qo = W.queries(hay, off, 4000, 50)
     _check_all(m, o, q, qo, 10)                                # builds the base image
     needles = W.unpack(q, qo)
@@ -142,10 +132,10 @@ def test_tombstones_and_pending_puts_under_the_window_major_sweep(ws_env):
     assert info["base_builds"] == 1 and info["n_tombstones"] == len(victims) and info["n_pending"] == 300
 
 
-def test_small_batches_and_small_haystacks_keep_the_needle_major_path(ws_env):
-    ws_env()
+def test_small_batches_and_small_haystacks_keep_the_needle_major_path():
     hay, off = W.geonames(600000, 80000, 41)
     m, o = _pair(hay, off)
+    _ws(m)
     q, qo = W.queries(hay, off, 500, 52)                       # default bounds: 500 needles is a small batch
     _check_all(m, o, q, qo, 10, took_ws=False)
 
@@ -154,20 +144,21 @@ _FUZZ_FIRST = int(os.environ.get("BLURRILY_FUZZ_FIRST", "0"))           # soak r
 
 
 @pytest.mark.parametrize("seed", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("BLURRILY_FUZZ_SEEDS", "6"))))
-def test_randomised_window_major_configurations(ws_env, seed):
+def test_randomised_window_major_configurations(seed):
     """Seeded random configurations of the window-major sweep -- haystack kind and size (5 to 11 windows),
     limit, cmin, reference numbering (dense / sparse), a sprinkle of deletes -- every row against the oracle."""
     rng = np.random.default_rng(1000 + seed)
     kind = ["geonames", "skewed", "words"][seed % 3]
     n = int(rng.integers(300_000, 700_000))
     limit = int(rng.choice([1, 2, 7, 10, 33, 100, 128]))
-    ws_env(WS_MIN_WINDOWS=2, WS_MIN_NEEDLES=500, WS_CMIN=int(rng.integers(1, 5)))
+    cmin = int(rng.integers(1, 5))
     hay, off = {"geonames": lambda: W.geonames(n, 50000, 60 + seed), "skewed": lambda: W.skewed(n, 60 + seed),
                 "words": lambda: W.words(n, 60 + seed)}[kind]()
     refs = np.arange(1, n + 1, dtype=np.uint32)
     if seed % 2:
         refs = (np.sort(rng.choice(2**31 - 2, size=n, replace=False)) + 1).astype(np.uint32)   # sparse references
     m, o = RawMap(), Oracle()
+    _ws(m, ws_min_windows=2, ws_min_needles=500, ws_cmin=cmin)
     m.put_many_packed(hay, off, refs)
     o.put_many(hay, off, refs)
     q, qo = W.queries(hay, off, 1500, 70 + seed)

@@ -10,10 +10,10 @@ import workloads as W
 from blurrily_amd import RawMap
 from blurrily_amd.map import _pack
 
-os.environ["BLURRILY_WSWEEP"] = "0"
 hay, off = W.bench_haystack("geonames", 1.0)
 n = len(off) - 1
 m = RawMap()
+m.set_option("wsweep", 0)
 m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
 m.sync_device()
 q, qo = W.queries(hay, off, 1024, 3000)

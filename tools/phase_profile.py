@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Phase breakdown of the find kernel (profiling build: make -C blurrily_amd/csrc profile).
+"""Phase breakdown of the find kernel: the counted build of the kernels (blurrily_storage_set_stats) also keeps
+wave 0's shader clocks per phase of the sweep.
 
 Usage on the GPU box:
-    BLURRILY_LIB=blurrily_amd/libblurrily_hip_prof.so python tools/phase_profile.py [scale] [n_queries]
+    python tools/phase_profile.py [scale] [n_queries]
 Prints shader clocks per window per phase as seen by wave 0 of each workgroup.
 """
 import ctypes as C
@@ -32,7 +33,8 @@ def main():
     m.sync_device()
     info = m.device_info()
     lib = _native.lib()
-    lib.blurrily_debug_phase_clocks.argtypes = [C.c_void_p, C.c_size_t]
+    lib.blurrily_debug_phase_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    m.set_stats(True)
     for batch in (512, nq):
         qp, qo = W.queries(hay, off, batch, 3000)
         t = time.perf_counter()
@@ -40,7 +42,7 @@ def main():
         dt = time.perf_counter() - t
         nwg = min(batch, 512)
         buf = np.zeros((nwg, 16), dtype=np.uint64)
-        assert lib.blurrily_debug_phase_clocks(buf.ctypes.data, nwg) == 0
+        assert lib.blurrily_debug_phase_clocks(m.handle, buf.ctypes.data, nwg) == 0
         tot_all = buf.sum(axis=0).astype(np.float64)
         tot = tot_all[:8]
         per_window = tot / (batch * info["n_windows"])

@@ -15,14 +15,16 @@ hay, off = W.bench_haystack(name, scale)
 n = len(off) - 1
 m = RawMap()
 m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+m.set_option("ws_min_slice", 0)          # (before the image is built: it then carries the bitmaps)
 m.sync_device()
 print("windows", m.device_info()["n_windows"], "bytes", m.device_info()["device_bytes"], flush=True)
 q, qo = W.queries(hay, off, nq, 3000)
-os.environ["BLURRILY_WS_MIN_SLICE"] = "0"
+m.set_option("ws_min_slice", 0)
 res = {}
-for label, env in (("needle-major", {"BLURRILY_WSWEEP": "0"}), ("window-major cmin2", {"BLURRILY_WSWEEP": "1", "BLURRILY_WS_CMIN": "2"}),
-                   ("window-major cmin1", {"BLURRILY_WS_CMIN": "1"}), ("window-major cmin3", {"BLURRILY_WS_CMIN": "3"})):
-    os.environ.update(env)
+for label, opts in (("needle-major", {"wsweep": 0}), ("window-major cmin2", {"wsweep": 1, "ws_cmin": 2}),
+                    ("window-major cmin1", {"ws_cmin": 1}), ("window-major cmin3", {"ws_cmin": 3})):
+    for k, v in opts.items():
+        m.set_option(k, v)
     m.find_batch_packed(q, qo, limit)
     m.set_timing(True)
     ts = []

@@ -15,12 +15,10 @@ hay, off = W.bench_haystack(name, scale)
 n = len(off) - 1
 m = RawMap()
 m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+m.set_option("ws_min_slice", int(os.environ.get("WS_MIN_SLICE", "0")))
 m.sync_device()
 q, qo = W.queries(hay, off, nq, 3000)
 m.set_timing(True)
-os.environ.setdefault("BLURRILY_WS_MIN_SLICE", "0")
-for dbg in os.environ.get("WS_DEBUG_LIST", "0").split(","):
-    os.environ["BLURRILY_WS_DEBUG"] = dbg
-    for _ in range(reps):
-        m.find_batch_packed(q, qo, limit)
-        print("debug", dbg, "kernel ms", m.device_info()["last_find_kernel_ms"], flush=True)
+for _ in range(reps):
+    m.find_batch_packed(q, qo, limit)
+    print("kernel ms", m.device_info()["last_find_kernel_ms"], flush=True)

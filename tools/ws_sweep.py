@@ -12,15 +12,15 @@ limit = W.BENCH_WORKLOADS[name]["limit"]
 hay, off = W.bench_haystack(name, scale)
 n = len(off) - 1
 q, qo = W.queries(hay, off, nq, 3000)
-os.environ["BLURRILY_WS_MIN_SLICE"] = "0"
 for dense in (512, 1024, 2048, 4096):
-    os.environ["BLURRILY_DENSE_MIN"] = str(dense)
     m = RawMap()
+    m.set_option("ws_min_slice", 0)
+    m.set_option("dense_min", dense)
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     m.sync_device()
     m.set_timing(True)
     for cmin in (2, 3, 4, 5):
-        os.environ["BLURRILY_WS_CMIN"] = str(cmin)
+        m.set_option("ws_cmin", cmin)
         m.find_batch_packed(q, qo, limit)
         m.find_batch_packed(q, qo, limit)
         print(f"{name} dense>={dense} cmin={cmin}: {m.device_info()['last_find_kernel_ms']:.1f} ms  index {m.device_info()['device_bytes'] / 1e6:.0f} MB", flush=True)
