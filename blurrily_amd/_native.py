@@ -103,6 +103,7 @@ def lib():
         "blurrily_storage_set_timing": (None, [vp, C.c_int]),
         "blurrily_storage_set_stats": (None, [vp, C.c_int]),
         "blurrily_storage_find_stats": (C.c_int, [vp, C.c_void_p]),
+        "blurrily_storage_find_path_flags": (C.c_int, [vp, C.c_void_p, C.c_size_t]),
         "blurrily_storage_set_option": (C.c_int, [vp, C.c_char_p, C.c_longlong]),
         "blurrily_storage_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_longlong)]),
     }
@@ -122,5 +123,5 @@ EXPORTED_SYMBOLS = (
     "blurrily_storage_sync_device", "blurrily_tokeniser_parse_string",
     "blurrily_storage_device_info", "blurrily_storage_set_timing",
     "blurrily_storage_set_stats", "blurrily_storage_find_stats",
-    "blurrily_storage_set_option", "blurrily_storage_get_option",
+    "blurrily_storage_set_option", "blurrily_storage_get_option", "blurrily_storage_find_path_flags",
 )

@@ -102,6 +102,8 @@ struct trigram_map_t {
   bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
   unsigned long long* d_stats = nullptr;   // [kStatSlots], zeroed by every run_find while collecting
   unsigned long long* d_phase = nullptr;   // [kPhaseWorkgroups][16] phase clocks of the counted build's last launch
+  DeviceBuffer ws_flags;                   // [n] path flags of the last find while collecting (FindArgs::path_flags)
+  size_t      n_flags = 0;
   double      last_find_ms = 0.0, last_tok_ms = 0.0;
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_in, ws_io_out;
@@ -279,6 +281,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
     BLURRILY_HIP_TRY(hipMemsetAsync(m->d_phase, 0, kPhaseBytes, stream));
     a.phase_clocks = m->d_phase;
+    a.path_flags = static_cast<uint32_t*>(m->ws_flags.p);   // (sized and zeroed by run_find)
   }
   // every launch gets its own zeroed queue word (scalars[2..63]); recycled in stream order
   uint32_t queue_slot = 2;
@@ -407,6 +410,9 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   if (m->collect_stats) {
     if (!m->d_stats) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), kStatAllSlots * 8));
     BLURRILY_HIP_TRY(hipMemsetAsync(m->d_stats, 0, kStatAllSlots * 8, stream));
+    if (m->ws_flags.reserve(std::max<size_t>(n, 1) * sizeof(uint32_t), stream) < 0) return -1;
+    BLURRILY_HIP_TRY(hipMemsetAsync(m->ws_flags.p, 0, std::max<size_t>(n, 1) * sizeof(uint32_t), stream));
+    m->n_flags = n;
   }
   if (apply_tombstones(m, stream) < 0) return -1;
   if (log_empty(m))
@@ -473,7 +479,7 @@ int blurrily_storage_close(trigram_map* haystack) {
     m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
-    m->ws_io_out.release(); m->ws_tomb.release();
+    m->ws_io_out.release(); m->ws_tomb.release(); m->ws_flags.release();
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     delete m->host;
     delete m;
@@ -764,6 +770,14 @@ int blurrily_storage_find_stats(trigram_map m, uint64_t* out8) {
   DeviceScope scope(m->dev.device);
   BLURRILY_HIP_TRY(hipDeviceSynchronize());
   BLURRILY_HIP_TRY(hipMemcpy(out8, m->d_stats, kStatSlots * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int blurrily_storage_find_path_flags(trigram_map m, uint32_t* out, size_t n) {
+  if (!m->ws_flags.p || n > m->n_flags) { errno = EINVAL; return -1; }
+  DeviceScope scope(m->dev.device);
+  BLURRILY_HIP_TRY(hipDeviceSynchronize());
+  BLURRILY_HIP_TRY(hipMemcpy(out, m->ws_flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -71,6 +71,34 @@ struct FindArgs {
   // optional request counters of a launch (nullptr: off; see kStat* below) -- what the kernels asked of
   // the memory system and of the LDS, counted exactly from wave-uniform values
   unsigned long long* stats;
+  // counted build only: which paths of the kernels a needle's find went through, one word per needle, OR of
+  // kPath* below (blurrily_storage_find_path_flags: the parity tests sample every class)
+  uint32_t*       path_flags;
+};
+
+// bits of FindArgs::path_flags
+enum : uint32_t {
+  kPathNibble       = 1u << 0,    // swept windows with 4-bit counters, two per step (sweep_coop<Nib>)
+  kPathByte         = 1u << 1,    // swept windows with byte counters (sweep_coop<uint8_t>)
+  kPathColdStart    = 1u << 2,    // no threshold yet: the first scan's bound found by bisection
+  kPathResweep      = 1u << 3,    // a step swept again after the candidate pool overflowed
+  kPathCompaction   = 1u << 4,    // the pool compacted in mid-sweep (threshold tightened)
+  kPathSkipped      = 1u << 5,    // steps stepped over: no reference of the window can reach the threshold
+  kPathRingOverflow = 1u << 6,    // more units than the descriptor ring holds: every wave walked the table
+  kPathPipelined    = 1u << 7,    // sweep_pipelined (65..128 distinct trigrams, wide counters)
+  kPathWide         = 1u << 8,    // 16-bit counters (more than 127 distinct trigrams)
+  kPathChunked      = 1u << 9,    // slice table staged through LDS in chunks (more than 128 distinct trigrams)
+  kPathRanged       = 1u << 10,   // latency mode: the needle's windows cut into ranges, merged afterwards
+  kPathMultiPass    = 1u << 11,   // a later pass of a limit larger than the pool (floor key)
+  kPathTombstone    = 1u << 12,   // a candidate rejected because its reference was deleted since the build
+  kPathOwnOnly      = 1u << 13,   // phase 1 of the window-major sweep (own length class only)
+  kPathWsTask       = 1u << 14,   // window-major sweep: at least one (needle, window) task ran
+  kPathWsLeftOut    = 1u << 15,   //   ... with dense slices left out of the count and probed through bitmaps
+  kPathWsRobust     = 1u << 16,   //   ... the robust scan (no threshold yet, or after a candidate-list overflow)
+  kPathWsCandOv     = 1u << 17,   //   ... the candidate list overflowed
+  kPathWsPoolOv     = 1u << 18,   //   ... the candidate pool overflowed
+  kPathWsWide       = 1u << 19,   //   ... byte counters over the two halves of the window
+  kPathWsTableWalk  = 1u << 20,   //   ... more than 64 units: the waves walked the published slice table
 };
 
 // slots of FindArgs::stats

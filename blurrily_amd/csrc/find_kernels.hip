@@ -52,10 +52,13 @@
 // in its innermost loops, measured on one box, tools/ab_probe.py.)  This is the file's only build switch.
 #ifdef BLURRILY_COUNTED
 #define STATS(A) ((A).stats)
+// one thread marks the path a needle's find takes (FindArgs::path_flags)
+#define PATH_FLAG(A, q_, bits_) do { if ((A).path_flags && (threadIdx.x & 63u) == 0) atomicOr(&(A).path_flags[q_], (bits_)); } while (0)
 #define BLURRILY_KERNELS_BEGIN namespace counted {
 #define BLURRILY_KERNELS_END }
 #else
 #define STATS(A) (static_cast<unsigned long long*>(nullptr))
+#define PATH_FLAG(A, q_, bits_) do { } while (0)
 #define BLURRILY_KERNELS_BEGIN
 #define BLURRILY_KERNELS_END
 #endif
@@ -570,6 +573,7 @@ __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t ca
 
 // State of one needle's sweep that every phase needs.
 struct Needle {
+  uint32_t q;                       // its number in the batch (path flags of the counted build only)
   uint32_t T;                       // distinct trigrams
   bool has_floor;                   // later pass of a limit larger than the pool (floor key in Control)
 };
@@ -589,7 +593,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
                                           const unsigned long long* floor, const uint32_t* tomb,
                                           unsigned long long* pool, const uint32_t pool_cap, uint32_t* pool_n,
                                           uint32_t* overflow, uint32_t wbase, uint32_t wlen,
-                                          const uint32_t need_floor = 0) {
+                                          const uint32_t need_floor = 0, uint32_t* path_flag = nullptr) {
   using P = Packing<CT>;
   using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x;
@@ -611,6 +615,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
           const unsigned long long key = (static_cast<unsigned long long>(nd.T - cnt) << 32) | rank;
           bool pass = key <= thr;
           if (nd.has_floor) pass = pass && key > *floor;
+          if (path_flag && tomb && pass && ((tomb[rank >> 5] >> (rank & 31)) & 1u) != 0) atomicOr(path_flag, kPathTombstone);
           if (tomb) pass = pass && ((tomb[rank >> 5] >> (rank & 31)) & 1u) == 0;   // deleted since the build
           if (pass) {
             const uint32_t at = atomicAdd(pool_n, 1u);
@@ -690,17 +695,20 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
   const unsigned long long thr = ctl->thr;
   uint32_t need_floor = 0;
   // (not with a floor key or tombstones: candidates they reject would be counted as present)
-  if (thr == kKeyInf && !nd.has_floor && !A.tomb && nd.T > 1)
+  if (thr == kKeyInf && !nd.has_floor && !A.tomb && nd.T > 1) {
     need_floor = cold_start_need<CT, NT>(cnt128, nd.T, A.keep, ctl, wlen);
+    PATH_FLAG(A, nd.q, kPathColdStart);
+  }
   scan_core<CT, NT>(cnt128, nd, thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow,
-                    wbase, wlen, need_floor);
+                    wbase, wlen, need_floor, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
 }
 
 // ---- select: keep the pool small and the threshold tight.  Returns true when the pool
 // overflowed during the scan of this window, i.e. the window has to be swept again.
 template <int NT>
 __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned long long* pool, Control* ctl,
-                                                  uint32_t wbase, uint32_t wlen) {
+                                                  uint32_t wbase, uint32_t wlen, uint32_t q_flag) {
+  (void)q_flag;
   const uint32_t ov = ctl->overflow;
   const uint32_t pn = ctl->pool_n;
   // compact when the pool fills up -- or as soon as it holds `keep` candidates for the first
@@ -708,6 +716,7 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
   if (!(ov || pn > A.pool_cap / 2 || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
   if (STATS(A) && threadIdx.x == 0) atomicAdd(&STATS(A)[kStatCompactions], 1ull);
   compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+  PATH_FLAG(A, q_flag, ov ? kPathCompaction | kPathResweep : kPathCompaction);
   if (!ov) return false;
   // The pool overflowed mid-window: candidates of this window were lost.  Keep the
   // tightened threshold (the keep-th best of a subset is a valid bound), forget this
@@ -760,6 +769,7 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint32_t* s_a = s_tab;
   uint32_t* s_b = s_tab + kCodeChunk;
+  PATH_FLAG(A, nd.q, kPathChunked);
   for (uint32_t w = w0; w < w1; ++w) {
     const uint32_t wbase = w * kWindowRanks;
     const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
@@ -781,7 +791,7 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
       if (!touched) break;                                      // nothing of this needle in the window
       scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
       __syncthreads();
-      redo = select_after_scan<NT>(A, pool, ctl, wbase, wlen);
+      redo = select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q);
     } while (redo);
   }
 }
@@ -906,6 +916,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 #define BLURRILY_SKIPPABLE(w_) \
   ((w_) < w1 && min(tc, A.win_max_tri[w_]) < matches_needed(ctl->thr, tc, (w_) * kWindowRanks))
 
+  PATH_FLAG(A, nd.q, kPathPipelined);
   BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(0u), ca0, cb0, ca1, cb1);
   BLURRILY_FETCH_TABLE(BLURRILY_WIN_AT(1u), na0, nb0, na1, nb1);
   BLURRILY_LOAD_HEAD(ca0, cb0, ca1, cb1);
@@ -936,6 +947,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     // behind the barriers of select)
     if (BLURRILY_SKIPPABLE(BLURRILY_WIN_AT(i + 1))) {
       head_any = false; head_more = false;
+      PATH_FLAG(A, nd.q, kPathSkipped);
     } else {
       BLURRILY_LOAD_HEAD(na0, nb0, na1, nb1);
     }
@@ -946,7 +958,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
         PHASE_MARK(5);                                          // scan
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
-        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
+        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
         count_rest<CT, kNW>(A.ent, cnt32, ca0, cb0, ca1, cb1, two_slots, wid, lane, 0u, STATS(A));   // overflow: again
         __syncthreads();
       }
@@ -1116,6 +1128,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // loop, the 64-bit threshold arithmetic and the step bookkeeping themselves (the kernel keeps its VALU
   // pipes ~85 % busy, half of it such bookkeeping repeated in every wave, profiles/r02_old_pmc.txt).
   uint32_t my_i = 0;                                            // visit index of the table this wave holds
+  PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
   if (wid == BLURRILY_PRODUCER(0u)) {
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
     BLURRILY_PRODUCE(0u, ta, tb, ta1, tb1);
@@ -1143,6 +1156,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     const bool has_turn = wid == BLURRILY_PRODUCER(e + 1) || wid == BLURRILY_PRODUCER(e + 2);
     if (has_turn) __builtin_amdgcn_s_setprio(2);
     if (n_units == kRingOverflow) {
+      PATH_FLAG(A, nd.q, kPathRingOverflow);
       BLURRILY_COUNT_WALK(p);
     } else {
       BLURRILY_COUNT_UNITS(s, n_units);
@@ -1166,6 +1180,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       __builtin_amdgcn_s_setprio(3);
       const uint32_t chosen = __builtin_amdgcn_readfirstlane(ring->visit[(e + 1) & 1]);
       BLURRILY_NEXT_VISIT(chosen + 1, my_i);
+      if (my_i != chosen + 1) PATH_FLAG(A, nd.q, kPathSkipped);
       if (lane == 0) ring->visit[e & 1] = my_i;
       BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);
       __builtin_amdgcn_s_setprio(0);
@@ -1179,7 +1194,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
         PHASE_MARK(5);                                          // scan
         __syncthreads();                                        // counters are zero again
         PHASE_MARK(6);                                          // barrier after scan
-        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen)) break;
+        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
         ++st_redo;
         if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
         else BLURRILY_COUNT_UNITS(s, n_units);
@@ -1271,6 +1286,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     const uint32_t w1 = RANGED ? min(A.n_windows, 2 * uint32_t(uint64_t(n_pairs) * (range + 1) / R))
                                : own_only ? min(A.n_windows, own0 + 2) : A.n_windows;
     Needle nd;
+    nd.q = q;
     nd.T = A.q_ntri[q];
     if (!A.work_list && nd.T > (SHORT ? 64u : 127u)) { // longer needles: the mid / wide-counter launches
       if (RANGED && tid == 0) A.part_count[slot] = 0;
@@ -1299,6 +1315,8 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     __syncthreads();
 
     PHASE_NEEDLE(10);
+    PATH_FLAG(A, q, (sizeof(CT) == 2 ? kPathWide : 0u) | (RANGED ? kPathRanged : 0u) | (nd.has_floor ? kPathMultiPass : 0u) |
+                    (own_only ? kPathOwnOnly : 0u));
     __builtin_amdgcn_s_setprio(0);
     if (STATS(A) && tid == 0) atomicAdd(&STATS(A)[kStatTasks], 1ull);
     // (a macro, not a closure: closures capturing the kernel arguments end up in scratch memory)
@@ -1875,6 +1893,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
         ws_barrier();
         bool changed = false;
         bool robust = cnt0 < keep;                           // no threshold yet: nothing can be left out
+        PATH_FLAG(A, q, robust ? kPathWsTask | kPathWsRobust : kPathWsTask);
         WS_CLOCK(1);
 
         for (;;) {                                           // again after an overflow (rare)
@@ -1926,6 +1945,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
           const uint32_t need_eff = need - L;                // >= cmin >= 1 when L > 0
           if (n_units == 0) break;                           // nothing to count: nothing can reach need_eff >= 1
           ++st_steps;
+          PATH_FLAG(A, q, (L ? kPathWsLeftOut : 0u) | (wide ? kPathWsWide : 0u) | (n_units > 64 ? kPathWsTableWalk : 0u));
           WS_CLOCK(6);                                       // the left-out set chosen, the units published
 
           for (uint32_t h = 0; h < (wide ? 2u : 1u); ++h) {
@@ -2033,7 +2053,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
           WS_CLOCK(4);
           // ---- select ---------------------------------------------------------------------------
           const uint32_t cov = s_ctl.cand_ov;
-          const uint32_t ov = ctl->overflow | cov, pn = ctl->pool_n;
+          const uint32_t pov = ctl->overflow;
+          const uint32_t ov = pov | cov, pn = ctl->pool_n;
           if (!ov && pn == pool_at_start) break;                           // nothing was admitted
           ws_barrier();
           if (tid == 0) { s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
@@ -2045,6 +2066,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
           // window's survivors and sweep it again (every pass shrinks the admitted set) -- the robust way
           // if it was the candidate list that overflowed.
           ++st_redo;
+          PATH_FLAG(A, q, (cov ? kPathWsCandOv | kPathWsRobust : 0u) | (pov ? kPathWsPoolOv : 0u));
           if (cov) robust = true;
           if (tid == 0) {
             uint32_t jj = 0;

@@ -215,6 +215,20 @@ class RawMap:
         self._check_open()
         self._lib.blurrily_storage_set_stats(self._h, 1 if enabled else 0)
 
+    # bits of find_path_flags() (csrc/find_kernels.h: kPath*)
+    PATH_FLAGS = ("nibble", "byte", "cold_start", "resweep", "compaction", "skipped", "ring_overflow", "pipelined",
+                  "wide", "chunked", "ranged", "multi_pass", "tombstone", "own_only", "ws_task", "ws_left_out",
+                  "ws_robust", "ws_cand_overflow", "ws_pool_overflow", "ws_wide", "ws_table_walk")
+
+    def find_path_flags(self, n):
+        """Per needle of the last find call made while set_stats(True): which kernel paths its find took
+        (uint32 array; bit i = PATH_FLAGS[i])."""
+        self._check_open()
+        out = np.zeros(n, dtype=np.uint32)
+        if self._lib.blurrily_storage_find_path_flags(self._h, out.ctypes.data, n) < 0:
+            _raise_errno()
+        return out
+
     def set_option(self, key, value):
         """A tunable of this map (include/blurrily_storage.h: blurrily_storage_set_option)."""
         self._check_open()

@@ -177,6 +177,13 @@ void blurrily_storage_set_timing(trigram_map haystack, int enabled);
  * Collecting costs a few scalar instructions per wave-load; leave it off when timing. */
 void blurrily_storage_set_stats(trigram_map haystack, int enabled);
 int  blurrily_storage_find_stats(trigram_map haystack, uint64_t* out8);
+/* While the counters are on, every needle of a find call also gets a word saying which paths of the
+ * kernels its find went through (4-bit / byte / 16-bit counters, cold-start bisection, pool overflow
+ * and re-sweep, windows stepped over, latency-mode ranges, the window-major sweep's left-out slices,
+ * robust scan, overflows ...: the kPath* bits of csrc/find_kernels.h, mirrored in blurrily_amd/map.py).
+ * Copies the words of the first n needles of the LAST such call.  The parity tests use it to compare
+ * needles of every class row for row.  0, or -1 with errno EINVAL (no such call, n too large). */
+int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_t n);
 
 /* Tunables (no reference counterpart; nothing on the find path reads the environment).
  * Per map -- read by the map's next find; calls on one map are serial, as in the reference:

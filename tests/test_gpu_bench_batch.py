@@ -8,7 +8,14 @@ same tools/workloads.py functions bench.py uses.
     spec/integration_spec.rb:37-42), no reference twice, 1 <= matches <= T, counts <= limit,
     weight == strlen of the indexed string (storage.c:409), and d_nb_entries equal to the
     oracle's nb_entries (storage.c:498-503) -- all 1 M of them;
-  * 1 200 sampled needles row for row against the oracle;
+  * the first 100 000 needles row for row, through SHA-256 digests of oracle-produced result blocks
+    (tests/golden/digest_*.json, tools/make_digests.py; configs[1] and configs[4]: that is the whole batch);
+  * stratified by kernel path: a second launch with the kernels' request counters on yields, per needle, the
+    paths its find went through (blurrily_storage_find_path_flags: 4-bit / byte counters, cold start, pool
+    overflow and re-sweep, windows stepped over, left-out slices, robust scan ...); its rows must equal the
+    timed launch's, every class that occurs in the batch must occur among the digest-covered needles, and a
+    further sample drawn class by class from the REST of the batch is compared with the oracle row for row;
+  * sampled needles of the whole batch row for row against the oracle;
   * the host-buffer entry point on a slice of the same batch gives the same rows.
 """
 import ctypes as C
@@ -18,7 +25,7 @@ import pytest
 
 import workloads as W
 from blurrily_amd import RawMap, _native
-from helpers import Oracle
+from helpers import Oracle, block_digests, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -36,8 +43,8 @@ def _order_ok(rows, counts, limit):
     return ok
 
 
-@pytest.mark.parametrize("name,n_sample", [("geonames", 1200), ("words", 3000), ("skewed", 300)])
-def test_the_benched_call_on_the_benched_batch(name, n_sample):
+@pytest.mark.parametrize("name,n_sample,per_class", [("geonames", 1200, 150), ("words", 3000, 0), ("skewed", 300, 0)])
+def test_the_benched_call_on_the_benched_batch(name, n_sample, per_class):
     import torch
     spec = W.BENCH_WORKLOADS[name]
     limit = spec["limit"]
@@ -95,6 +102,56 @@ def test_the_benched_call_on_the_benched_batch(name, n_sample):
         c = int(counts[q])
         assert np.array_equal(rows[q, :c], want["rows"][k, :c]), (int(q), rows[q, :c].tolist(),
                                                                   want["rows"][k, :c].tolist())
+
+    # ---- the first 100 000 needles, row for row, through digests of the oracle's result blocks ------
+    import os
+    from helpers import GOLDEN
+    covered = min(n_q, 100_000)
+    if os.path.exists(os.path.join(GOLDEN, f"digest_{name}.json")) or not os.environ.get("BLURRILY_DIGESTS_PENDING"):
+        gold = load_golden(f"digest_{name}.json")
+        assert gold["limit"] == limit and gold["needles"] == covered
+        got = block_digests(rows[:covered], counts[:covered], gold["block"])
+        bad = [k for k, (a, b) in enumerate(zip(got, gold["digests"])) if a != b]
+        assert not bad and len(got) == len(gold["digests"]), f"result blocks {bad[:8]} (of {gold['block']} needles) differ"
+        assert int(counts[:covered].sum()) == gold["sum_counts"]
+
+    # ---- by kernel path: the counted build says which paths every needle took ----------------------
+    m.set_stats(True)
+    d_results2 = torch.full_like(d_results, -1)
+    d_counts2 = torch.full_like(d_counts, -1)
+    res = lib.blurrily_storage_find_batch_device(m.handle, d_packed.data_ptr(), int(qo[-1]), d_off.data_ptr(), n_q,
+                                                 limit, d_results2.data_ptr(), d_counts2.data_ptr(), 0, stream)
+    assert res == 0, C.get_errno()
+    torch.cuda.synchronize()
+    flags = m.find_path_flags(n_q)
+    m.set_stats(False)
+    counts2 = d_counts2.cpu().numpy().view(np.uint32).astype(np.int64)
+    rows2 = d_results2.cpu().numpy().view(np.uint32)
+    live = np.arange(limit)[None, :] < counts[:, None]
+    assert np.array_equal(counts2, counts) and np.array_equal(np.where(live[:, :, None], rows2, 0),
+                                                              np.where(live[:, :, None], rows, 0))
+    assert flags.all(), "a needle without any path flag"
+    hist = {nm: int(((flags >> b) & 1).sum()) for b, nm in enumerate(m.PATH_FLAGS) if ((flags >> b) & 1).any()}
+    print(f"{name}: needles by kernel path {hist}")
+    rest_idx = []
+    for b, nm in enumerate(m.PATH_FLAGS):
+        has = np.nonzero((flags >> b) & 1)[0]
+        if len(has) == 0:
+            continue
+        in_cover = int((has < covered).sum())
+        # a class of at least 1 in 10 000 needles is present among the digest-covered needles ...
+        assert in_cover > 0 or len(has) * 10000 < n_q, (nm, len(has))
+        # ... and sampled from the rest of the batch as well
+        outside = has[has >= covered]
+        if len(outside):
+            rest_idx.append(np.random.default_rng(b).choice(outside, size=min(len(outside), per_class), replace=False))
+    if rest_idx:
+        idx2 = np.unique(np.concatenate(rest_idx)).astype(np.uint32)
+        want2 = o.batch(qp, qo, idx=idx2, limit=limit)
+        assert np.array_equal(counts[idx2], want2["counts"])
+        for k, q in enumerate(idx2):
+            c = int(counts[q])
+            assert np.array_equal(rows[q, :c], want2["rows"][k, :c]), (int(q), hex(int(flags[q])))
 
     # ---- the host-buffer entry point agrees on a slice of the batch --------------------------
     lo, hi = n_q // 2, n_q // 2 + 5000
