@@ -15,14 +15,21 @@ block; the region ends only when every gather has arrived.
 Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carries
 
   roofline       the position of the dominant kernel against the HBM roofline, from PHYSICAL
-                 bytes: what the kernels requested of the memory system in one launch -- counted
-                 exactly by the kernels themselves (blurrily_storage_set_stats) in an extra,
-                 untimed launch of this very run -- over the HIP-event kernel time of the timed
-                 steps.  `frac` = that rate / 8 TB/s, always <= 1.  The SURVEY.md section 8(d)
-                 algorithmic figure (the reference's 8 bytes per matched entry) is kept beside it
-                 as algorithmic_*: it exceeds the peak because a posting costs 2 bytes in HBM and
-                 windows / slices that cannot change the answer are never read.  An `lds` line
-                 gives the LDS-atomic rate against the ds_add ceiling of the guide.
+                 bytes measured IN THIS RUN: what the kernels requested of the memory system in one
+                 launch -- counted exactly by the kernels themselves (blurrily_storage_set_stats,
+                 the counted build of the same kernels) in an extra, untimed launch -- over the
+                 HIP-event kernel time of the timed steps.  `achieved` / `frac` / `traffic` are
+                 those bytes (L2 hits included: 6 % at configs[2]), frac = rate / 8 TB/s <= 1.
+                 `pmc` beside it is the memory-side figure of a separate rocprofv3 --pmc run
+                 (profiles/traffic_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, Infinity-Cache
+                 hits included), stamped with the hash of the kernel sources it was profiled at
+                 and marked stale -- loudly, on stderr -- when they have changed since.  gfx950
+                 exposes no DRAM-only byte counter to rocprofv3 (`hbm_only_frac` null, see
+                 DESIGN.md section 5).  The SURVEY.md section 8(d) algorithmic figure (the
+                 reference's 8 bytes per matched entry) is kept as algorithmic_*: it exceeds the
+                 peak because a posting costs 2 bytes in HBM and windows / slices that cannot
+                 change the answer are never read -- never an efficiency.  An `lds` line gives the
+                 LDS-atomic rate against the measured ds_add ceiling.
   cpu_baseline   (N=1) the reference's own C -- oracle/_ref -- timed on one host core on a bounded
                  prefix of the step's needles, whose rows are compared with the rows the GPU wrote
                  for the same needles in the timed launch: `parity_checked` needles, exit status 1
@@ -46,6 +53,22 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (imported before the HIP library so both share one HIP runtime)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# what the parity claims of this line do NOT rest on the reference for
+UNPINNED = ["reference put (storage.c:398-473 needs search_tree.c, i.e. ruby.h: haystacks reach oracle/_ref as "
+            ".trigrams files written by this library)",
+            "normalize_string on non-ASCII input (ActiveSupport 4.2 NFKD tables absent; unicodedata used, "
+            "vectors frozen in tests/golden/normalize_vectors.json)"]
+
+
+def kernel_source_hash():
+    """sha256 over the sources the find path's kernels and their launch logic are built from: what a PMC profile
+    must have been taken at to describe this run."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("find_kernels.hip", "find_kernels.h", "device_index.hip", "device_index.h", "c_abi.hip"):
+        with open(os.path.join(ROOT, "blurrily_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 # LDS atomics: no-return ds_add_u32 lanes per second, whole chip, MEASURED (tools/micro/lds_atomic_rate.hip,
 # profiles/r02_lds_atomic_rate.txt: conflict-free addresses, find_kernel's residency; 6.97e12 with random
 # addresses).  MI355X_MICROARCH.md's ds_write_b32 figure -- 16 lanes per clock per CU -- gives 9.83e12 at 2.4 GHz;
@@ -285,24 +308,36 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     req_bytes = (2 * st["posting_entries"] + 4 * st["table_words"] + 4 * st["probes"] + out_bytes + 2 * needle_bytes)
     req_gbs = req_bytes / (k_ms * 1e-3) / 1e9
     lds_lanes = st["posting_entries"] / (k_ms * 1e-3)
-    # memory-side bytes per step from the rocprofv3 --pmc passes of this workload (a separate run of this
-    # command under the profiler, profiles/): the L2's fabric-side counters, i.e. HBM + Infinity Cache
-    pmc_bytes, pmc_src = None, None
+    # Beside it: memory-side bytes per step from the rocprofv3 --pmc passes of this workload (a SEPARATE run of
+    # this command under the profiler, profiles/traffic_latest.json): the L2's fabric-side counters, i.e. HBM +
+    # Infinity Cache.  Only as good as the build it was taken at: stamped, and stale when the sources changed.
+    pmc = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath) and args.scale == 1.0:
         try:
-            pmc_bytes = json.load(open(tpath)).get(name)
-            pmc_src = ("profiles/traffic_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KiB of this workload's find kernels, "
-                       "rocprofv3 --pmc, separate run (tools/collect_profiles.sh); includes Infinity-Cache hits")
-        except Exception:
-            pmc_bytes = None
-    phys_bytes = pmc_bytes if pmc_bytes else req_bytes
-    phys_gbs = phys_bytes / (k_ms * 1e-3) / 1e9
+            prof = json.load(open(tpath))
+            if prof.get(name):
+                at, now = prof.get("kernel_source_hash"), kernel_source_hash()
+                pmc = {"bytes_per_step": prof[name], "gbs": prof[name] / (k_ms * 1e-3) / 1e9,
+                       "frac": prof[name] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "profiled_at_commit": prof.get("commit"), "profiled_at_source_hash": at,
+                       "stale": at != now,
+                       "source": "profiles/traffic_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KiB of this workload's find "
+                                 "kernels, rocprofv3 --pmc, separate run (tools/collect_profiles.sh); Infinity-Cache hits included"}
+                if pmc["stale"]:
+                    log(f"WARNING: profiles/traffic_latest.json was profiled at kernel sources {at}, this run is {now}: "
+                        f"the PMC traffic figure of '{name}' is STALE (re-run tools/collect_profiles.sh)")
+        except Exception as e:
+            pmc = {"error": str(e)}
 
     totals = torch.tensor([float(sum_nb), k_ms, float(np.mean(gather_ms)) if gather_ms else 0.0],
                           dtype=torch.float64, device=coll_dev)
     per_rank = None
+    device_ids, device_names = [local_rank], [torch.cuda.get_device_name(local_rank)]
     if world > 1:
+        ids = [None] * world
+        dist.all_gather_object(ids, (torch.cuda.current_device(), torch.cuda.get_device_name(torch.cuda.current_device())))
+        device_ids, device_names = [i for i, _ in ids], [nm for _, nm in ids]
         allr = [torch.zeros_like(totals) for _ in range(world)]
         dist.all_gather(allr, totals)
         per_rank = [[float(x) for x in t.tolist()] for t in allr]
@@ -348,14 +383,17 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             "entries_per_query": sum_nb / n_q,
             "kernel_ms": k_ms,
             "roofline": {
-                "bound": "hbm", "achieved": phys_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": phys_gbs / HBM_PEAK_GBS,
-                "traffic": phys_bytes,
-                "traffic_source": pmc_src or "no PMC file for this workload: the bytes the kernels REQUESTED (below), an "
-                                             "upper bound on memory-side bytes only when nothing is re-used from cache",
                 # what the kernels asked of the memory system in one launch sequence of this batch, counted exactly
                 # in-kernel (blurrily_storage_set_stats) in an extra untimed launch of THIS run; L2 hits included
+                "bound": "hbm", "achieved": req_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": req_gbs / HBM_PEAK_GBS,
+                "traffic": req_bytes,
+                "traffic_source": "in-run: bytes the kernels requested (postings, slice tables, bitmap probes, needles, "
+                                  "rows), counted by the counted build of the kernels in an untimed launch of this batch",
                 "requested_bytes": req_bytes, "requested_gbs": req_gbs,
+                "pmc": pmc,
+                "hbm_only_frac": None,        # no DRAM-only byte counter on gfx950's rocprofv3 list
+                "kernel_source_hash": kernel_source_hash(),
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if st["probes"] else
                            "find_kernel<uint8_t,1024>"),
                 "kernel_ms": k_ms,
@@ -369,7 +407,15 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "counted_launch_rows_equal_timed": stats_rows_equal,
                 "resident_index_bytes": int(info["device_bytes"])},
         }
+        out["unpinned"] = UNPINNED
         if world > 1:
+            # what the collective ran on: enough to tell an RCCL run over N devices from anything else
+            out["collective"] = {
+                "backend": dist.get_backend(), "world": dist.get_world_size(),
+                "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version())
+                                 if dist.get_backend() == "nccl" else None),
+                "device_ids": device_ids, "device_names": sorted(set(device_names)),
+                "op": "gather to rank 0, one per step, async (issued behind the search, waited for before the block is reused)"}
             out["per_rank"] = {"kernel_ms": [p[1] for p in per_rank], "gather_ms": [p[2] for p in per_rank]}
             out["gather_ms"] = float(np.mean(gather_ms))
             out["gather_bytes_per_rank"] = int(block.buf.numel() * 4)

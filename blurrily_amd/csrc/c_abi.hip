@@ -108,6 +108,16 @@ struct trigram_map_t {
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_in, ws_io_out;
   unsigned char* h_stage = nullptr;     // pinned host staging: [kStageBytes in | kStageBytes out]
+  // large host-buffer batches go in chunks through a three-stream pipeline (find_batch_chunked)
+  uint32_t    host_chunk = 131072;      // needles per chunk (option "host_chunk"; 0: never chunk)
+  struct Pipe {
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t  ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    unsigned char* h_in[2] = {nullptr, nullptr};     // pinned
+    unsigned char* h_out[2] = {nullptr, nullptr};
+    size_t h_in_bytes = 0, h_out_bytes = 0;
+    DeviceBuffer d_in[2], d_out[2];
+  } pipe;
 };
 
 namespace {
@@ -481,6 +491,13 @@ int blurrily_storage_close(trigram_map* haystack) {
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
     m->ws_io_out.release(); m->ws_tomb.release(); m->ws_flags.release();
     if (m->h_stage) (void)hipHostFree(m->h_stage);
+    for (int i = 0; i < 2; ++i) {
+      if (m->pipe.h_in[i]) (void)hipHostFree(m->pipe.h_in[i]);
+      if (m->pipe.h_out[i]) (void)hipHostFree(m->pipe.h_out[i]);
+      m->pipe.d_in[i].release(); m->pipe.d_out[i].release();
+      for (hipEvent_t e : {m->pipe.ev_in[i], m->pipe.ev_run[i], m->pipe.ev_out[i]}) if (e) (void)hipEventDestroy(e);
+    }
+    for (hipStream_t s : {m->pipe.s_in, m->pipe.s_run, m->pipe.s_out}) if (s) (void)hipStreamDestroy(s);
     delete m->host;
     delete m;
   }
@@ -558,6 +575,108 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
 
 }  // extern "C"
 
+// A large host-buffer batch in chunks through three streams: while chunk k is searched (s_run), chunk k+1's
+// needles travel to the device (s_in) and chunk k-1's rows travel back (s_out) -- both through pinned staging,
+// which the host fills / drains meanwhile.  Two slots by turns; a slot is reused only after its rows have been
+// copied out to the caller.  Each element is still exactly one blurrily_storage_find.
+static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
+                              trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii, size_t chunk) {
+  auto& P = m->pipe;
+  if (!P.s_in) {
+    for (hipStream_t* s : {&P.s_in, &P.s_run, &P.s_out}) BLURRILY_HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i)
+      for (hipEvent_t* e : {&P.ev_in[i], &P.ev_run[i], &P.ev_out[i]})
+        BLURRILY_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  // staging sizes: the largest chunk's bytes in (rebased offsets | needles) and out (counts | flags | rows)
+  size_t max_packed = 0;
+  for (size_t a = 0; a < n; a += chunk) {
+    const size_t b = std::min(n, a + chunk);
+    max_packed = std::max<size_t>(max_packed, size_t(offsets[b] - offsets[a]));
+  }
+  const size_t off_cap = align_up((chunk + 1) * sizeof(uint64_t), 256);
+  const size_t cnt_cap = align_up(chunk * sizeof(uint32_t), 256);
+  const size_t flag_cap = raw ? cnt_cap : 0;
+  const size_t in_cap = off_cap + std::max<size_t>(max_packed, 16);
+  const size_t out_cap = cnt_cap + flag_cap + std::max<size_t>(chunk * size_t(limit) * sizeof(trigram_match_t), 16);
+  if (P.h_in_bytes < in_cap || P.h_out_bytes < out_cap) {
+    BLURRILY_HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) {
+      if (P.h_in[i]) (void)hipHostFree(P.h_in[i]);
+      if (P.h_out[i]) (void)hipHostFree(P.h_out[i]);
+      P.h_in[i] = P.h_out[i] = nullptr;
+    }
+    P.h_in_bytes = P.h_out_bytes = 0;
+    for (int i = 0; i < 2; ++i) {
+      BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&P.h_in[i]), in_cap));
+      BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&P.h_out[i]), out_cap));
+    }
+    P.h_in_bytes = in_cap; P.h_out_bytes = out_cap;
+  }
+  for (int i = 0; i < 2; ++i)
+    if (P.d_in[i].reserve(in_cap, P.s_run) < 0 || P.d_out[i].reserve(out_cap, P.s_run) < 0) return -1;
+
+  struct Span { size_t a, b; };
+  Span in_slot[2] = {{0, 0}, {0, 0}};
+  // rows of the chunk slot `i` holds, from pinned staging to the caller's buffers (behind its D2H)
+  auto drain = [&](int i) -> int {
+    const Span sp = in_slot[i];
+    if (sp.b == sp.a) return 0;
+    BLURRILY_HIP_TRY(hipEventSynchronize(P.ev_out[i]));
+    const size_t c = sp.b - sp.a;
+    std::memcpy(counts + sp.a, P.h_out[i], c * sizeof(uint32_t));
+    if (raw && non_ascii) std::memcpy(non_ascii + sp.a, P.h_out[i] + cnt_cap, c * sizeof(uint32_t));
+    if (limit)
+      std::memcpy(results + sp.a * size_t(limit), P.h_out[i] + cnt_cap + flag_cap, c * size_t(limit) * sizeof(trigram_match_t));
+    in_slot[i] = {0, 0};
+    return 0;
+  };
+  size_t k = 0;
+  for (size_t a = 0; a < n; a += chunk, ++k) {
+    const size_t b = std::min(n, a + chunk), c = b - a;
+    const int i = int(k & 1);
+    if (drain(i) < 0) return -1;                                  // chunk k-2: its staging and device blocks are free again
+    // ---- stage chunk k: offsets rebased to the chunk, its needles; how long they can be --------------
+    uint64_t* h_off = reinterpret_cast<uint64_t*>(P.h_in[i]);
+    const uint64_t base = offsets[a];
+    size_t max_len = 0;
+    for (size_t j = 0; j <= c; ++j) h_off[j] = offsets[a + j] - base;
+    const size_t bytes = size_t(offsets[b] - base);
+    if (bytes) std::memcpy(P.h_in[i] + off_cap, packed + base, bytes);
+    for (size_t j = 0; j < c && max_len <= 126; ++j) {            // (what the launches need to know: > 63, > 126)
+      const size_t cap = size_t(h_off[j + 1] - h_off[j]);
+      if (cap <= max_len) continue;
+      const char* s = packed + base + h_off[j];
+      const void* nul = std::memchr(s, 0, cap);
+      max_len = std::max(max_len, nul ? size_t(static_cast<const char*>(nul) - s) : cap);
+    }
+    unsigned char* d_in = static_cast<unsigned char*>(P.d_in[i].p);
+    unsigned char* d_out = static_cast<unsigned char*>(P.d_out[i].p);
+    BLURRILY_HIP_TRY(hipMemcpyAsync(d_in, P.h_in[i], off_cap + std::max<size_t>(bytes, 16), hipMemcpyHostToDevice, P.s_in));
+    BLURRILY_HIP_TRY(hipEventRecord(P.ev_in[i], P.s_in));
+    // ---- search it ---------------------------------------------------------------------------------
+    BLURRILY_HIP_TRY(hipStreamWaitEvent(P.s_run, P.ev_in[i], 0));
+    const uint64_t* d_offsets = reinterpret_cast<const uint64_t*>(d_in);
+    char* d_packed = reinterpret_cast<char*>(d_in + off_cap);
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(d_out);
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_out + cnt_cap);
+    trigram_match d_rows = reinterpret_cast<trigram_match>(d_out + cnt_cap + flag_cap);
+    if (raw && launch_normalise(d_packed, d_offsets, uint32_t(c), d_packed, d_flags, P.s_run) < 0) return -1;
+    if (run_find(m, d_packed, bytes, d_offsets, c, limit, d_rows, d_counts, nullptr, max_len > 126, max_len > 63,
+                 P.s_run) < 0)
+      return -1;
+    BLURRILY_HIP_TRY(hipEventRecord(P.ev_run[i], P.s_run));
+    // ---- and send its rows home ----------------------------------------------------------------------
+    BLURRILY_HIP_TRY(hipStreamWaitEvent(P.s_out, P.ev_run[i], 0));
+    BLURRILY_HIP_TRY(hipMemcpyAsync(P.h_out[i], d_out, cnt_cap + flag_cap + c * size_t(limit) * sizeof(trigram_match_t),
+                                    hipMemcpyDeviceToHost, P.s_out));
+    BLURRILY_HIP_TRY(hipEventRecord(P.ev_out[i], P.s_out));
+    in_slot[i] = {a, b};
+  }
+  if (drain(int(k & 1)) < 0 || drain(int((k + 1) & 1)) < 0) return -1;
+  return 0;
+}
+
 // Host-buffer batch: needles in, rows out.  raw = the needles are un-normalised ASCII (see
 // blurrily_storage_find_batch_raw); non_ascii (raw only, may be null) receives the per-needle flags.
 static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
@@ -585,6 +704,13 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
   if (ensure_device(m) < 0) return -1;
   if (m->timing && !m->ev[0])
     for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
+  // (timing and request counters describe ONE launch sequence: those runs stay in one piece)
+  if (m->host_chunk && n >= 2 * size_t(m->host_chunk) && !m->timing && !m->collect_stats) {
+    size_t chunk = m->host_chunk;
+    const size_t row_cap = size_t(32) << 20;                      // at most 32 MiB of rows per chunk in pinned staging
+    while (chunk > 1024 && chunk * size_t(limit) * sizeof(trigram_match_t) > row_cap) chunk >>= 1;
+    return find_batch_chunked(m, packed, offsets, n, limit, results, counts, raw, non_ascii, chunk);
+  }
 
   hipStream_t stream = nullptr;
   const size_t packed_bytes = size_t(offsets[n]);
@@ -702,7 +828,7 @@ namespace {
 struct OptionSlot { const char* key; long long lo, hi; };
 constexpr OptionSlot kMapOptions[] = {
     {"wsweep", 0, 1}, {"ws_cmin", 1, 64}, {"ws_min_windows", 0, 1 << 20}, {"ws_min_needles", 0, 1ll << 32},
-    {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}};
+    {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}, {"host_chunk", 0, 1ll << 30}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -731,6 +857,7 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
       if (m->build_opt.dense_min != uint32_t(value) && m->dev.device >= 0) m->log_overflow = true;
       m->build_opt.dense_min = uint32_t(value);
       break;
+    case 6: m->host_chunk = uint32_t(value); break;
   }
   return 0;
 }
@@ -750,6 +877,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 3: *value = m->ws_min_needles; return 0;
     case 4: *value = m->build_opt.ws_min_slice; return 0;
     case 5: *value = m->build_opt.dense_min; return 0;
+    case 6: *value = m->host_chunk; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -588,22 +588,30 @@ __device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint3
 }
 
 // ---- scan: admit counters that can still reach the top `keep`, clear them ----------------
+// `need`: counters below it cannot enter the pool (the caller's bound: from the threshold, or the cold start's);
+// `cap`: no counter of this sweep exceeds it.  The threshold itself (*thr_p, in LDS: it does not change while a
+// scan runs) is read only where a counter is harvested.
 template <typename CT, int NT>
-__device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const unsigned long long thr,
-                                          const unsigned long long* floor, const uint32_t* tomb,
-                                          unsigned long long* pool, const uint32_t pool_cap, uint32_t* pool_n,
-                                          uint32_t* overflow, uint32_t wbase, uint32_t wlen,
-                                          const uint32_t need_floor = 0, uint32_t* path_flag = nullptr) {
+__device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const uint32_t need, const uint32_t cap,
+                                          const unsigned long long* thr_p, const unsigned long long* floor,
+                                          const uint32_t* tomb, unsigned long long* pool, const uint32_t pool_cap,
+                                          uint32_t* pool_n, uint32_t* overflow, uint32_t wbase, uint32_t wlen,
+                                          uint32_t* path_flag = nullptr) {
   using P = Packing<CT>;
   using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x;
-  const uint32_t need = max(matches_needed(thr, nd.T, wbase), need_floor);
   const uint32_t nvec = S::nvec(wlen);
   __builtin_amdgcn_s_setprio(1);                         // the scan is a chain of LDS round trips: it goes ahead of the other workgroup's counting
-  if (need <= min(nd.T, S::kMaxCount)) {                 // (a 4-bit window holds no counter above 15)
+  // the zero quad the scanned vectors are cleared with, materialised once per scan (opaque: a plain zero vector
+  // would be hoisted out of the sweep and held -- or spilled -- for the whole needle)
+  uint4 zq;
+  asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+               : "=v"(zq.x), "=v"(zq.y), "=v"(zq.z), "=v"(zq.w));
+  if (need <= cap) {                                     // (a 4-bit window holds no counter above 15)
     const typename S::Need nq = S::prepare(need);
     // slow path of one vector: some counter reached `need`
     auto harvest = [&](const uint4 v, const uint32_t i) {
+      const unsigned long long thr = *thr_p;
       auto word = [&](const uint32_t wv, const uint32_t j) {
         uint32_t m = S::hits(wv, nq);
         while (m) {
@@ -630,13 +638,9 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
     // zero quad -- 3.5% slower; read-and-clear in one ds_wrxchg_rtn_b64 per 8 bytes: +0.5%, noise.)
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint4 v = cnt128[i];
-      // An opaque zero, materialised here: a loop-invariant zero vector would be hoisted, held
-      // in four VGPRs for the whole sweep and spilled to scratch under the 64-VGPR budget.
-      uint32_t z = 0;
-      asm volatile("" : "+v"(z));
-      cnt128[i] = make_uint4(z, z, z, z);
+      cnt128[i] = zq;
       v = S::mask_pad(v, i);
-      // one SWAR test per vector: the top bit of a field is set iff its counter >= need
+      // one AND per vector, then one SWAR test: the top bit of a field is set iff its counter >= need
       if (S::maybe(v, nq) && S::any_hit(v, nq)) {
         __builtin_amdgcn_s_setprio(3);     // a wave that found something is the one the scan barrier will wait for
         harvest(v, i);
@@ -644,11 +648,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
     }
   } else {
     // nothing in this window can enter the pool any more: just clear the counters
-    for (uint32_t i = tid; i < nvec; i += NT) {
-      uint32_t z = 0;
-      asm volatile("" : "+v"(z));
-      cnt128[i] = make_uint4(z, z, z, z);
-    }
+    for (uint32_t i = tid; i < nvec; i += NT) cnt128[i] = zq;
   }
   S::clear_unreached_pad(cnt128, nvec, tid);
   __builtin_amdgcn_s_setprio(0);
@@ -699,8 +699,9 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
     need_floor = cold_start_need<CT, NT>(cnt128, nd.T, A.keep, ctl, wlen);
     PATH_FLAG(A, nd.q, kPathColdStart);
   }
-  scan_core<CT, NT>(cnt128, nd, thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow,
-                    wbase, wlen, need_floor, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
+  scan_core<CT, NT>(cnt128, nd, max(matches_needed(thr, nd.T, wbase), need_floor), min(nd.T, ScanTraits<CT>::kMaxCount),
+                    &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow, wbase, wlen,
+                    STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
 }
 
 // ---- select: keep the pool small and the threshold tight.  Returns true when the pool
@@ -1002,11 +1003,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
 
 struct UnitRing {
   uint2    desc[2][kRingUnits];                                 // .x first entry of the unit, .y end of its slice
-  uint32_t n_units[2];                                          // kRingOverflow: too many units, walk the table
-  uint32_t step[2];                                             // which step the slot's units belong to (past the end: none)
+  // what a step starts with, ONE 8-byte read: .x the step the slot's units belong to (past the end: none left),
+  // .y the number of units (kRingWalk: too many, walk the table) | the scan's admission bound << 16 (0: the slow
+  // scan, which works it out itself -- cold start)
+  uint2    hdr[2];
   uint32_t visit[2];                                            // the visit index chosen most recently, by turns
 };
-constexpr uint32_t kRingOverflow = 0xFFFFFFFFu;
+constexpr uint32_t kRingWalk = 0xFFFFu;
+static_assert(kRingUnits < kRingWalk, "a unit count is sixteen bits of the step header");
+
+// why sweep_coop's hot loop was left
+enum : uint32_t { kLeftDone = 0, kLeftWalk = 1, kLeftSlowScan = 2, kLeftSelect = 3 };
 
 template <typename CT, int NT>
 __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
@@ -1024,6 +1031,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t code = own ? codes[lane] : 0u;
   const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
   const uint32_t n_visit = v1 - v0;
+  uint4* const cnt128 = reinterpret_cast<uint4*>(cnt32);
 #define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
   // most trigrams of the needle a reference of the step's window(s) can hold
 #define BLURRILY_WMT_AT(i_, out_)                                                \
@@ -1063,28 +1071,42 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       A1 = A.slice_off[idx_]; B1 = A.slice_off[idx_ + 1];                        \
     }                                                                            \
   } while (0)
+  // The header of step step_ in ring slot s_, by lane 0 of the publishing wave: the step, its unit count and the
+  // bound its scan admits counters from -- worked out HERE, once, from the threshold as it is now, instead of by
+  // every wave behind the count barrier.  The threshold can only tighten until that scan runs (in the select of
+  // the step in between), so the published bound is at most too low: the scan then looks at a few counters more,
+  // and every counter it looks at is tested against the threshold of the moment before it enters the pool.
+  // 0 = no threshold yet and a cold start due: the slow scan.
+#define BLURRILY_PUBLISH_HDR(s_, step_, nu_)                                     \
+  do {                                                                           \
+    const unsigned long long thr_ = ctl->thr;                                    \
+    uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFFFu); \
+    if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
+    if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | (need_ << 16));   \
+  } while (0)
   // this wave publishes the units of the table into ring slot s_: a lane's even-window units,
   // then its odd-window units
-#define BLURRILY_PRODUCE(s_, A0, B0, A1, B1)                                     \
+#define BLURRILY_PRODUCE(s_, step_, A0, B0, A1, B1)                              \
   do {                                                                           \
     const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
     const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
     if (total_ > kRingUnits) {                                                   \
-      if (lane == 0) ring->n_units[s_] = kRingOverflow;                          \
+      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk);                                \
     } else {                                                                     \
       uint32_t at_ = incl_ - units0_ - units1_;                                  \
       for (uint32_t j_ = 0; j_ < units0_; ++j_, ++at_)                           \
         ring->desc[s_][at_] = make_uint2(A0 + j_ * 512, B0);                     \
       for (uint32_t j_ = 0; j_ < units1_; ++j_, ++at_)                           \
         ring->desc[s_][at_] = make_uint2((A1 + j_ * 512) | 1u, B1);              \
-      if (lane == 0) ring->n_units[s_] = total_;                                 \
+      BLURRILY_PUBLISH_HDR(s_, step_, total_);                                   \
     }                                                                            \
   } while (0)
-  // the units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
-  // atomics run while the next unit's load is in flight
-  // (which lanes loaded a group travels as a lane predicate -- an SGPR pair -- beside the unit in flight: no
-  // sentinels to fill idle lanes with, no liveness test before the atomics)
+  // The units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
+  // atomics run while the next unit's load is in flight.  Which lanes loaded a group travels as a lane
+  // predicate -- an SGPR pair -- beside the unit in flight: no sentinels to fill idle lanes with, no liveness
+  // test before the atomics.  A unit's address is a scalar base (its first entry) plus the lane's 16 bytes:
+  // nothing per unit and lane but the load itself and one compare.
 #define BLURRILY_COUNT_UNITS(s_, n_)                                             \
   do {                                                                           \
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
@@ -1094,11 +1116,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       const uint2 d_ = ring->desc[s_][k_];                                       \
       const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                  \
       const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                  \
-      const uint32_t c_ = (x_ & ~7u) + lane * 8;                                 \
-      const bool live_ = c_ < y_;                                                \
+      const uint32_t x0_ = x_ & ~7u;                                             \
+      const bool live_ = lane8 < y_ - x0_;                                       \
       uint4 v_ = pend_;                                                          \
-      if (live_) v_ = *reinterpret_cast<const uint4*>(A.ent + c_);               \
-      if (STATS(A)) st_ent += min(512u, y_ - (x_ & ~7u));                        \
+      if (live_) v_ = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x0_) + lane16); \
+      if (STATS(A)) st_ent += min(512u, y_ - x0_);                               \
       if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);               \
       pend_ = v_; pend_h_ = x_ & 1u; pend_live_ = live_;                         \
     }                                                                            \
@@ -1118,89 +1140,122 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
                                 if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
   } while (0)
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
+  // The two turns a step has behind its units.  The wave whose turn it is publishes the next visited step (its
+  // table arrived a step ago); the wave after it chooses the step after the next (the threshold only changes
+  // behind select's barriers) and fetches its table, which travels during the barrier and the scan.
+#define BLURRILY_TAKE_TURNS(e_, s_)                                              \
+  do {                                                                           \
+    if (wid == BLURRILY_PRODUCER((e_) + 1)) {                                    \
+      __builtin_amdgcn_s_setprio(3);                /* the wave the count barrier waits for goes first */ \
+      if (my_i < n_visit) {                                                      \
+        BLURRILY_PRODUCE((s_) ^ 1u, BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);   \
+      } else if (lane == 0) {                                                    \
+        ring->hdr[(s_) ^ 1u] = make_uint2(v1, 0u);                               \
+      }                                                                          \
+      __builtin_amdgcn_s_setprio(0);                                             \
+    }                                                                            \
+    PHASE_MARK(7);                                  /* (producer turn) next step's units published */ \
+    if (wid == BLURRILY_PRODUCER((e_) + 2)) {                                    \
+      __builtin_amdgcn_s_setprio(3);                                             \
+      const uint32_t chosen_ = __builtin_amdgcn_readfirstlane(ring->visit[((e_) + 1) & 1]); \
+      BLURRILY_NEXT_VISIT(chosen_ + 1, my_i);                                    \
+      if (my_i != chosen_ + 1) PATH_FLAG(A, nd.q, kPathSkipped);                 \
+      if (lane == 0) ring->visit[(e_) & 1] = my_i;                               \
+      BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);            \
+      __builtin_amdgcn_s_setprio(0);                                             \
+    }                                                                            \
+  } while (0)
 
+  const uint32_t lane8 = lane * 8, lane16 = lane * 16;
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
   uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0;    // request counters (FindArgs::stats), wave-uniform
   // Which step comes next is decided by ONE wave per step -- the one that then fetches that step's table --
-  // and travels through LDS with the units: `step[slot]` beside `n_units[slot]`, the visit index chosen last in
-  // `visit[]`.  The other fifteen waves read two words per step instead of each running the window-bound
-  // loop, the 64-bit threshold arithmetic and the step bookkeeping themselves (the kernel keeps its VALU
-  // pipes ~85 % busy, half of it such bookkeeping repeated in every wave, profiles/r02_old_pmc.txt).
+  // and travels through LDS with the units (`hdr[slot]`; the visit index chosen last in `visit[]`).  The other
+  // fifteen waves read one header per step instead of each running the window-bound loop, the 64-bit threshold
+  // arithmetic and the step bookkeeping themselves.
   uint32_t my_i = 0;                                            // visit index of the table this wave holds
   PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
   if (wid == BLURRILY_PRODUCER(0u)) {
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
-    BLURRILY_PRODUCE(0u, ta, tb, ta1, tb1);
-    if (lane == 0) ring->step[0] = BLURRILY_STEP_AT(0u);
+    BLURRILY_PRODUCE(0u, BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
   }
   if (wid == BLURRILY_PRODUCER(1u)) {
     BLURRILY_NEXT_VISIT(1u, my_i);
     if (lane == 0) ring->visit[1] = my_i;
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);
   }
+  // a threshold exists (it is set by compact_pool only, i.e. outside the hot loop below: re-read behind every exit)
+  bool have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
+  const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
   __syncthreads();
 
-  for (uint32_t e = 0;; ++e) {
-    const uint32_t s = e & 1;
-    const uint32_t p = __builtin_amdgcn_readfirstlane(ring->step[s]);
-    if (p >= v1) break;                                         // no step left
-    const uint32_t n_units = __builtin_amdgcn_readfirstlane(ring->n_units[s]);
+  // The sweep is a HOT LOOP of steps that need nothing special -- header, units, turns, barrier, scan with the
+  // published bound, barrier, a glance at the pool -- and is left for everything else (more units than the ring
+  // holds; no threshold yet: the cold start's bisection; the pool to be compacted, perhaps the step swept again),
+  // which is dealt with behind it before the loop is entered again.  Kept apart so that what only the rare paths
+  // need is not held in registers, nor worked out, step after step.
+  uint32_t e = 0;
+  for (;;) {
+    uint32_t left, s, p, n_units;
+    for (;; ++e) {
+      s = e & 1;
+      const uint2 h_ = ring->hdr[s];
+      p = __builtin_amdgcn_readfirstlane(h_.x);
+      const uint32_t hy_ = __builtin_amdgcn_readfirstlane(h_.y);
+      n_units = hy_ & 0xFFFFu;
+      if (p >= v1) { left = kLeftDone; break; }                 // no step left
+      ++st_steps;
+      PHASE_MARK(0);                                            // loop overhead
+      // (the two waves with a turn to take behind their units are the ones the count barrier waits for: they
+      // issue ahead of the others from the start of the step)
+      if (wid == BLURRILY_PRODUCER(e + 1) || wid == BLURRILY_PRODUCER(e + 2)) __builtin_amdgcn_s_setprio(2);
+      if (n_units == kRingWalk) { left = kLeftWalk; break; }
+      BLURRILY_COUNT_UNITS(s, n_units);
+      PHASE_MARK(2);                                            // units counted
+      BLURRILY_TAKE_TURNS(e, s);
+      __syncthreads();                                          // counts and next descriptors visible
+      PHASE_MARK(3);                                            // barrier after count
+      if (n_units == 0) continue;                               // nothing of the needle in this step's windows
+      const uint32_t need = hy_ >> 16;
+      if (need == 0) { left = kLeftSlowScan; break; }
+      const uint32_t wbase = p * kWPS * kWindowRanks;
+      const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
+      scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n,
+                        &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
+      PHASE_MARK(5);                                            // scan
+      __syncthreads();                                          // counters are zero again
+      PHASE_MARK(6);                                            // barrier after scan
+      const uint2 c_ = *reinterpret_cast<const uint2*>(&ctl->pool_n);          // pool_n, overflow
+      const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x), ov_ = __builtin_amdgcn_readfirstlane(c_.y);
+      if (ov_ != 0 || pn_ > A.pool_cap / 2 || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
+    }
+    if (left == kLeftDone) break;
+    // ---- the rare paths of step p ----------------------------------------------------------------
     const uint32_t wbase = p * kWPS * kWindowRanks;
     const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-    ++st_steps;
-    PHASE_MARK(0);                                              // loop overhead
-    // ---- count step p --------------------------------------------------------------------
-    // (the two waves with a turn to take behind their units are the ones the count barrier waits for: they
-    // issue ahead of the others from the start of the step)
-    const bool has_turn = wid == BLURRILY_PRODUCER(e + 1) || wid == BLURRILY_PRODUCER(e + 2);
-    if (has_turn) __builtin_amdgcn_s_setprio(2);
-    if (n_units == kRingOverflow) {
+    if (left == kLeftWalk) {
       PATH_FLAG(A, nd.q, kPathRingOverflow);
       BLURRILY_COUNT_WALK(p);
-    } else {
-      BLURRILY_COUNT_UNITS(s, n_units);
+      BLURRILY_TAKE_TURNS(e, s);
+      __syncthreads();
     }
-    PHASE_MARK(2);                                              // units counted
-    // the wave whose turn it is publishes the next visited step (its table arrived a step ago)
-    if (wid == BLURRILY_PRODUCER(e + 1)) {
-      __builtin_amdgcn_s_setprio(3);                            // the wave the count barrier waits for goes first
-      if (my_i < n_visit) {
-        BLURRILY_PRODUCE(s ^ 1u, ta, tb, ta1, tb1);
-        if (lane == 0) ring->step[s ^ 1u] = BLURRILY_STEP_AT(my_i);
-      } else if (lane == 0) {
-        ring->n_units[s ^ 1u] = 0; ring->step[s ^ 1u] = v1;
-      }
-      __builtin_amdgcn_s_setprio(0);
-    }
-    PHASE_MARK(7);                                              // (producer turn) next step's units published
-    // the wave after it chooses the step after the next (the threshold only changes behind select's
-    // barriers) and fetches its table, which travels during the barrier and the scan
-    if (wid == BLURRILY_PRODUCER(e + 2)) {
-      __builtin_amdgcn_s_setprio(3);
-      const uint32_t chosen = __builtin_amdgcn_readfirstlane(ring->visit[(e + 1) & 1]);
-      BLURRILY_NEXT_VISIT(chosen + 1, my_i);
-      if (my_i != chosen + 1) PATH_FLAG(A, nd.q, kPathSkipped);
-      if (lane == 0) ring->visit[e & 1] = my_i;
-      BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    __syncthreads();                                            // counts and next descriptors visible
-    PHASE_MARK(3);                                              // barrier after count
-    PHASE_MARK(4);
-    if (n_units) {
-      for (;;) {
-        scan_window<CT, NT>(A, nd, reinterpret_cast<uint4*>(cnt32), pool, ctl, wbase, wlen);
-        PHASE_MARK(5);                                          // scan
-        __syncthreads();                                        // counters are zero again
-        PHASE_MARK(6);                                          // barrier after scan
-        if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
-        ++st_redo;
-        if (n_units == kRingOverflow) BLURRILY_COUNT_WALK(p);   // pool overflow: sweep step p again
-        else BLURRILY_COUNT_UNITS(s, n_units);
+    // kLeftSelect: the step is scanned, select_after_scan finds the pool as the hot loop saw it; else: scan first
+    bool scanned = left == kLeftSelect;
+    for (;;) {
+      if (!scanned) {
+        scan_window<CT, NT>(A, nd, cnt128, pool, ctl, wbase, wlen);
         __syncthreads();
       }
+      scanned = false;
+      if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
+      ++st_redo;                                                // pool overflow: sweep step p again
+      if (n_units == kRingWalk) BLURRILY_COUNT_WALK(p);
+      else BLURRILY_COUNT_UNITS(s, n_units);
+      __syncthreads();
     }
+    have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
+    ++e;
   }
   PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
@@ -1212,10 +1267,12 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     }
   }
   __syncthreads();                                              // ring and ctl quiet before the needle ends
+#undef BLURRILY_TAKE_TURNS
 #undef BLURRILY_PRODUCER
 #undef BLURRILY_COUNT_WALK
 #undef BLURRILY_COUNT_UNITS
 #undef BLURRILY_PRODUCE
+#undef BLURRILY_PUBLISH_HDR
 #undef BLURRILY_FETCH_TABLE
 #undef BLURRILY_NEXT_VISIT
 #undef BLURRILY_WMT_AT

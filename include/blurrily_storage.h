@@ -194,6 +194,9 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_cmin"         (3)     counted matches a left-out slice must leave
  *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing
  *                             it rebuilds the device image at the next find
+ *   "host_chunk"      (131072) blurrily_storage_find_batch / _raw: a batch of at least twice as many needles goes
+ *                             in chunks of this many through a three-stream pipeline (needles in, search, rows
+ *                             out overlap); 0 = always one piece
  * Process-wide -- `haystack` NULL:
  *   "host_threads"    (0 = hardware threads, at most 64) threads of put_many and of the device-image build
  *   "build_trace"     (0) wall time of the build stages on stderr

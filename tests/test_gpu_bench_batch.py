@@ -193,3 +193,36 @@ def test_bench_two_ranks_plumbing(tmp_path):
     # the gathers overlap the next step's search: both blocks went round and arrived as they were sent
     assert d["gather_overlapped"] is True and d["gather_checked"] == 2
     assert "cpu_baseline" not in d and "extra_configs" not in d
+    # which backend and devices the collective ran on (RCCL on the driver's multi-GPU runs; gloo here)
+    assert d["collective"]["backend"] == "gloo" and d["collective"]["world"] == 2 and len(d["collective"]["device_ids"]) == 2
+
+
+def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
+    """SCALE's N=1 point is `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the same code
+    path as plain `python bench.py` (no process group, no collective), hence the same line -- same config, same
+    in-run traffic figures, a value within run-to-run noise."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scale", "0.05",
+            "--no-extra", "--no-cpu-baseline", "--latency-probes", "0"]
+    lines = []
+    for launcher in ([], ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port)]):
+        res = subprocess.run([sys.executable] + launcher + tail, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]))
+    plain, launched = lines
+    assert plain["n_gpus"] == launched["n_gpus"] == 1 and "collective" not in launched and "per_rank" not in launched
+    assert plain["config"] == launched["config"] and plain["metric"] == launched["metric"]
+    assert plain["roofline"]["traffic"] == launched["roofline"]["traffic"]             # same batch, same kernels, same bytes
+    assert plain["roofline"]["counters"] == launched["roofline"]["counters"]
+    assert abs(plain["value"] - launched["value"]) / plain["value"] < 0.15, (plain["value"], launched["value"])
+    assert "unpinned" in plain and plain["roofline"]["hbm_only_frac"] is None

@@ -10,6 +10,16 @@ def test_spec_vectors(vec):
     assert normalize_string(vec["raw"]) == vec["normalized"]
 
 
+def test_frozen_non_ascii_vectors():
+    """Non-ASCII needles: expected strings worked out from a literal table of the Unicode Character Database's
+    (immutable) decomposition mappings, not from unicodedata (tools/make_normalize_vectors.py) -- the host-side
+    behaviour is frozen across Python / Unicode versions even though ActiveSupport's own tables stay unpinned."""
+    vectors = load_golden("normalize_vectors.json")["vectors"]
+    assert len(vectors) >= 200
+    for v in vectors:
+        assert normalize_string(v["raw"]) == v["normalized"], v
+
+
 @pytest.mark.parametrize("raw,want", [
     ("London", "london"),
     ("  many   spaces\there ", "many spaces here"),

@@ -140,3 +140,17 @@ def test_world_size_2_gathers_overlap_the_next_step(tmp_path):
     out = tmp_path / "result.txt"
     mp.spawn(_pipelined_worker, args=(2, _free_port(), 5, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+@pytest.mark.parametrize("n_needles", [64, 61, 5])      # even; ragged (shards of 8 and 7); fewer needles than ranks
+def test_world_size_8_gather_reassembles_in_order(tmp_path, n_needles):
+    """configs[3]'s rank count: eight contiguous shards (ragged, some empty), one gather."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(8, _free_port(), n_needles, 5, str(out)), nprocs=8, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_world_size_8_gathers_overlap_the_next_step(tmp_path):
+    out = tmp_path / "result.txt"
+    mp.spawn(_pipelined_worker, args=(8, _free_port(), 5, str(out)), nprocs=8, join=True)
+    assert out.read_text() == "ok"
