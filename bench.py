@@ -392,7 +392,11 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                                   "rows), counted by the counted build of the kernels in an untimed launch of this batch",
                 "requested_bytes": req_bytes, "requested_gbs": req_gbs,
                 "pmc": pmc,
-                "hbm_only_frac": None,        # no DRAM-only byte counter on gfx950's rocprofv3 list
+                # rocprofv3 -L on gfx950 lists no counter behind the Infinity Cache: TCC_EA0_RDREQ_DRAM counts the L2's
+                # requests DESTINED for local DRAM at the fabric interface, i.e. still in front of the 256 MiB cache
+                "hbm_only_frac": None,
+                "hbm_only_note": "no DRAM-only byte counter on gfx950 (TCC_EA0_RDREQ_DRAM = requests destined for DRAM, "
+                                 "counted before the Infinity Cache); the 470 MB index exceeds the 256 MiB cache",
                 "kernel_source_hash": kernel_source_hash(),
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if st["probes"] else
                            "find_kernel<uint8_t,1024>"),

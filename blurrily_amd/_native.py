@@ -29,6 +29,7 @@ class DeviceInfo(C.Structure):
         ("window_bits", C.c_uint32), ("n_entries", C.c_uint64), ("device_bytes", C.c_uint64),
         ("last_find_kernel_ms", C.c_double), ("last_tokenise_kernel_ms", C.c_double),
         ("n_pending", C.c_uint32), ("n_tombstones", C.c_uint32), ("base_builds", C.c_uint64),
+        ("mean_hit_slice", C.c_double), ("n_bitmaps", C.c_uint32), ("reserved_", C.c_uint32),
     ]
 
 

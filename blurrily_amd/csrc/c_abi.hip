@@ -815,6 +815,9 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
   info->n_pending = uint32_t(m->pending.size());
   info->n_tombstones = uint32_t(m->n_tomb);
   info->base_builds = m->base_builds;
+  info->mean_hit_slice = m->dev.mean_hit_slice;
+  info->n_bitmaps = m->dev.d_bm_id ? m->dev.n_bitmaps : 0;
+  info->reserved_ = 0;
   return 0;
 }
 

@@ -634,8 +634,10 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
       };
       word(v.x, 0); word(v.y, 1); word(v.z, 2); word(v.w, 3);
     };
-    // (Measured alternatives: a thread's vectors two at a time -- reads in flight together, one
-    // zero quad -- 3.5% slower; read-and-clear in one ds_wrxchg_rtn_b64 per 8 bytes: +0.5%, noise.)
+    // (Measured alternatives: a thread's vectors two at a time -- reads in flight together, one zero quad -- 3.5 %
+    // slower in round 1; all four of a thread in flight, round 3: 7.5 % slower (330.2 vs 307.4 ms per 500 k needles,
+    // same box): the LDS pipe is what the two resident workgroups share, a burst of reads lengthens the queue the
+    // other one's atomics wait in; read-and-clear in one ds_wrxchg_rtn_b64 per 8 bytes: +0.5 %, noise.)
     for (uint32_t i = tid; i < nvec; i += NT) {
       uint4 v = cnt128[i];
       cnt128[i] = zq;
@@ -1106,7 +1108,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // atomics run while the next unit's load is in flight.  Which lanes loaded a group travels as a lane
   // predicate -- an SGPR pair -- beside the unit in flight: no sentinels to fill idle lanes with, no liveness
   // test before the atomics.  A unit's address is a scalar base (its first entry) plus the lane's 16 bytes:
-  // nothing per unit and lane but the load itself and one compare.
+  // nothing per unit and lane but the load itself and one compare.  (Up to four of a wave's units loaded before
+  // the first is counted -- four loads in flight -- measured in round 3: 3.2 % SLOWER, 317.2 vs 307.4 ms.)
 #define BLURRILY_COUNT_UNITS(s_, n_)                                             \
   do {                                                                           \
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
@@ -1599,7 +1602,8 @@ __global__ void merge_rows_kernel(const trigram_match_t* __restrict__ a_rows, co
 constexpr int      kWsNT    = 256;             // (512 -- eight waves per task and SIMD, 64 VGPRs, 100 B of scratch -- measured:
                                                //  configs[2] 322 -> 346 ms per 300 k needles, configs[4] 82.3 -> 85.6 ms)
 constexpr uint32_t kWsNW    = kWsNT / 64;
-constexpr uint32_t kWsChunk = 256;             // most needles per queue pop (the task arrays in LDS)
+constexpr uint32_t kWsChunk = 64;              // most needles per queue pop (the task arrays in LDS; with 256 of them
+                                               // the per-task publication slots below would cost the fourth workgroup per CU)
 constexpr uint32_t kWsAhead = 4;               // units a wave loads before it counts the first of them
 constexpr uint32_t kWsCand  = 512;             // candidate list (rank | cold << 16): two per thread
 constexpr uint32_t kWsPool  = 256;             // candidate pool, >= 2 * kWsMaxKeep
@@ -1613,7 +1617,8 @@ struct WsControl {
   uint32_t cand_ov;           // the candidate list overflowed in this pass
   uint32_t n_tasks;
   uint32_t chunk;
-  uint32_t pub_units, pub_L, pub_wide;   // published by the task's owner wave with s_units / s_hot
+  // published by a task's owner wave with s_units[slot] / s_hot[slot], slot = the task's place in its group
+  uint32_t pub_units[kWsNW], pub_L[kWsNW], pub_wide[kWsNW];
 };
 
 __device__ __forceinline__ unsigned long long ws_load_key(const FindArgs& A, uint32_t q, uint32_t i) {
@@ -1854,8 +1859,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
   __shared__ uint32_t s_cand[kWsCand];
   __shared__ unsigned long long s_pool[kWsPool];
   __shared__ uint32_t s_task_q[kWsChunk], s_task_meta[kWsChunk], s_task_code[kWsChunk];
-  __shared__ uint2 s_units[64];                 // what the owner wave publishes: the units to count (first entry, slice end)
-  __shared__ uint32_t s_hot[64];                //   ... and the bitmaps of the slices it left out
+  __shared__ uint2 s_units[kWsNW][64];          // what a task's owner wave publishes: the units to count (first entry, slice end)
+  __shared__ uint32_t s_hot[kWsNW][64];         //   ... and the bitmaps of the slices it left out
   __shared__ WsControl s_ctl;
   uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
   Control* ctl = &s_ctl.c;
@@ -1896,7 +1901,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
       if (live) {
         const uint32_t at = atomicAdd(&s_ctl.n_tasks, 1u);
         s_task_q[at] = q;
-        s_task_meta[at] = T | (cnt << 8);
+        s_task_meta[at] = T | (cnt << 8) | (need << 16);     // (cnt <= keep <= 128, need <= 65: a byte each)
         s_task_code[at] = uint32_t(A.offsets[q]) + q;        // the needle's codes in qcodes (the host checked 32 bits)
       }
     }
@@ -1922,6 +1927,52 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
       nx_ta = soff[nx_code]; nx_tb = soff[nx_code + 1]; nx_bm = bmid[nx_code];            \
     }                                                                                     \
   } while (0)
+    // What a task's owner publishes for one pass over the window: which dense slices are left out (the L largest,
+    // L <= need - cmin), which units are to be counted; into slot `slot_` of s_units / s_hot / s_ctl.pub_*.
+#define WS_PUBLISH(slot_, T_, need_, robust_)                                                   \
+  do {                                                                                          \
+    const uint32_t l_max = (!(robust_) && (need_) > A.cmin) ? (need_) - A.cmin : 0u;            \
+    const uint32_t size = tb0 - ta;                                                             \
+    const bool dense = own && bm != kNoBitmap && size > 0;                                      \
+    uint32_t bigger = 0;                                                                        \
+    if (l_max)                                                                                  \
+      for (unsigned long long m = __ballot(dense); m; m &= m - 1) {                             \
+        const uint32_t u = __builtin_ctzll(m);                                                  \
+        const uint32_t su = __builtin_amdgcn_readlane(size, u);                                 \
+        bigger += (su > size || (su == size && u < lane)) ? 1u : 0u;                            \
+      }                                                                                         \
+    const bool skip = dense && bigger < l_max;                                                  \
+    const unsigned long long skipmask = __ballot(skip);                                         \
+    const uint32_t L_ = __popcll(skipmask);                                                     \
+    if (skip) s_hot[slot_][__popcll(skipmask & ((1ull << lane) - 1ull))] = bm;                  \
+    const uint32_t o_tb = skip ? ta : tb0;             /* slice ends after leaving slices out */ \
+    /* the units: slice t, 512 postings at a time; lane k keeps unit k */                       \
+    uint32_t nu = 0;                                                                            \
+    for (unsigned long long m = __ballot(o_tb > ta); m; m &= m - 1) {                           \
+      const uint32_t t = __builtin_ctzll(m);                                                    \
+      const uint32_t sa = __builtin_amdgcn_readlane(ta, t), sb = __builtin_amdgcn_readlane(o_tb, t); \
+      const uint32_t su = slice_units(sa, sb);                                                  \
+      if (nu + su <= 64) {                                                                      \
+        if (lane >= nu && lane < nu + su) s_units[slot_][lane] = make_uint2(sa + (lane - nu) * 512, sb); \
+      }                                                                                         \
+      nu += su;                                                                                 \
+    }                                                                                           \
+    if (nu > 64) {                                     /* too many to list: publish the slice table instead, */ \
+      s_units[slot_][lane] = make_uint2(ta, o_tb);     /* every wave walks it (lane t: slice t) */ \
+    }                                                                                           \
+    if (lane == 0) {                                                                            \
+      s_ctl.pub_units[slot_] = nu; s_ctl.pub_L[slot_] = L_;                                     \
+      s_ctl.pub_wide[slot_] = min((T_) - L_, wmt) > 15;  /* a cold count could overflow four bits */ \
+    }                                                                                           \
+  } while (0)
+    // a task's state (the needle's best keys so far) is requested a task ahead: thread t holds key t
+#define WS_FETCH_STATE(ti_)                                                               \
+  do {                                                                                    \
+    pf_key = kKeyInf;                                                                     \
+    if ((ti_) < n_tasks && tid < ((s_task_meta[ti_] >> 8) & 0xFFu)) pf_key = ws_load_key(A, s_task_q[ti_], tid); \
+  } while (0)
+    unsigned long long pf_key;
+    WS_FETCH_STATE(0u);
     WS_FETCH_CODES(wid);
     WS_FETCH_TABLE(wid);
     WS_FETCH_CODES(kWsNW + wid);
@@ -1934,21 +1985,29 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
       const uint32_t ta = nx_ta, tb0 = nx_tb, bm = nx_bm;     // (waits for the prefetched table)
       WS_FETCH_TABLE(g + kWsNW + wid);                        // next group: its codes arrived a group ago
       if (STATS(A) && my_ti < n_tasks) { st_tab += 3 * my_T; ++st_tasks; }
+      // Every wave publishes the first pass of its own task now, the four of them side by side -- from what the
+      // filter learnt of the needle (its threshold's bound, whether it has one) -- instead of one after the other
+      // with the other three waves waiting at a barrier (a fifth of a task's time, profiles/r03: "skipsel").  The
+      // barrier behind the first task's state makes all four visible.
+      if (my_ti < n_tasks) {
+        const uint32_t meta_ = s_task_meta[my_ti];
+        WS_PUBLISH(wid, my_T, meta_ >> 16, ((meta_ >> 8) & 0xFFu) < keep);
+      }
 
       for (uint32_t j = 0; j < kWsNW && g + j < n_tasks; ++j) {
         const uint32_t ti = g + j;
         const bool owner = wid == j;
         const uint32_t q = s_task_q[ti];
         const uint32_t meta = s_task_meta[ti];
-        const uint32_t T = meta & 0xFFu, cnt0 = meta >> 8;
-        // ---- the needle's state: its best keys so far ------------------------------------------
-        unsigned long long my_key = kKeyInf;
-        if (tid < cnt0) my_key = ws_load_key(A, q, tid);
+        const uint32_t T = meta & 0xFFu, cnt0 = (meta >> 8) & 0xFFu;
+        // ---- the needle's state: its best keys so far (requested a task ago) --------------------
+        const unsigned long long my_key = pf_key;
+        WS_FETCH_STATE(ti + 1);
         if (tid < cnt0) s_pool[tid] = my_key;
         if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
         if (tid == keep - 1 || (tid == 0 && cnt0 < keep)) ctl->thr = cnt0 >= keep ? my_key : kKeyInf;
         ws_barrier();
-        bool changed = false;
+        bool changed = false, first_pass = true;
         bool robust = cnt0 < keep;                           // no threshold yet: nothing can be left out
         PATH_FLAG(A, q, robust ? kPathWsTask | kPathWsRobust : kPathWsTask);
         WS_CLOCK(1);
@@ -1958,47 +2017,15 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
           const uint32_t pool_at_start = ctl->pool_n;
           const uint32_t need = matches_needed(thr, T, wbase);
           if (min(T, wmt) < need) break;                     // (the threshold tightened in an earlier pass)
-          // ---- owner: which dense slices are left out (the L largest, L <= need - cmin), which units
-          // are to be counted; published through s_units / s_hot / s_ctl.pub_* -------------------------
-          uint32_t o_tb = 0;                                 // owner's slice ends after leaving slices out
-          if (owner) {
-            const uint32_t l_max = (!robust && need > A.cmin) ? need - A.cmin : 0u;
-            const uint32_t size = tb0 - ta;
-            const bool dense = own && bm != kNoBitmap && size > 0;
-            uint32_t bigger = 0;
-            if (l_max)
-              for (unsigned long long m = __ballot(dense); m; m &= m - 1) {
-                const uint32_t u = __builtin_ctzll(m);
-                const uint32_t su = __builtin_amdgcn_readlane(size, u);
-                bigger += (su > size || (su == size && u < lane)) ? 1u : 0u;
-              }
-            const bool skip = dense && bigger < l_max;
-            const unsigned long long skipmask = __ballot(skip);
-            const uint32_t L = __popcll(skipmask);
-            if (skip) s_hot[__popcll(skipmask & ((1ull << lane) - 1ull))] = bm;
-            o_tb = skip ? ta : tb0;
-            // the units: slice t, 512 postings at a time; lane k keeps unit k
-            uint32_t nu = 0;
-            for (unsigned long long m = __ballot(o_tb > ta); m; m &= m - 1) {
-              const uint32_t t = __builtin_ctzll(m);
-              const uint32_t sa = __builtin_amdgcn_readlane(ta, t), sb = __builtin_amdgcn_readlane(o_tb, t);
-              const uint32_t su = slice_units(sa, sb);
-              if (nu + su <= 64) {
-                if (lane >= nu && lane < nu + su) s_units[lane] = make_uint2(sa + (lane - nu) * 512, sb);
-              }
-              nu += su;
-            }
-            if (nu > 64) {                                   // too many to list: publish the slice table instead,
-              s_units[lane] = make_uint2(ta, o_tb);          // every wave walks it (lane t: slice t)
-            }
-            if (lane == 0) {
-              s_ctl.pub_units = nu; s_ctl.pub_L = L;
-              s_ctl.pub_wide = min(T - L, wmt) > 15;         // a cold count could overflow four bits
-            }
+          // (the first pass was published when the group began; a later one -- the threshold tightened, or the robust
+          // way after an overflow -- by the owner now)
+          if (!first_pass) {
+            if (owner) WS_PUBLISH(j, T, need, robust);
+            ws_barrier();
           }
-          ws_barrier();
-          const uint32_t n_units = s_ctl.pub_units, L = s_ctl.pub_L;
-          const bool wide = s_ctl.pub_wide != 0;
+          first_pass = false;
+          const uint32_t n_units = s_ctl.pub_units[j], L = s_ctl.pub_L[j];
+          const bool wide = s_ctl.pub_wide[j] != 0;
           const uint32_t need_eff = need - L;                // >= cmin >= 1 when L > 0
           if (n_units == 0) break;                           // nothing to count: nothing can reach need_eff >= 1
           ++st_steps;
@@ -2013,7 +2040,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
 #pragma unroll
                 for (uint32_t i = 0; i < kWsAhead; ++i) {
                   const uint32_t k = k0 + i * kWsNW;
-                  const uint2 d = s_units[min(k, 63u)];
+                  const uint2 d = s_units[j][min(k, 63u)];
                   const uint32_t c = __builtin_amdgcn_readfirstlane(d.x);
                   const uint32_t e = k < n_units ? __builtin_amdgcn_readfirstlane(d.y) : 0u;
                   u[i] = load_group(A.ent, c + lane * 8, e);
@@ -2026,7 +2053,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
               }
             } else {
               // the published slice table: this wave's units of every slice (unit i of slice t: wave (t + i) mod 4)
-              const uint2 d = s_units[lane];
+              const uint2 d = s_units[j][lane];
               const uint32_t xa = d.x, xb = d.y;
               uint32_t k = 0;
               uint4 pend = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
@@ -2093,7 +2120,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
                 for (uint32_t i = 0; i < 4; ++i) {
                   x0[i] = x1[i] = 0;
                   if (i0 + i < L) {                                        // (uniform)
-                    const uint32_t id = __builtin_amdgcn_readfirstlane(s_hot[i0 + i]);
+                    const uint32_t id = __builtin_amdgcn_readfirstlane(s_hot[j][i0 + i]);
                     const uint32_t* bmw = A.bitmaps + size_t(id) * kBitmapWords;
                     if (has0) x0[i] = bmw[r0 >> 5];
                     if (has1) x1[i] = bmw[r1 >> 5];
@@ -2150,6 +2177,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
       }
       WS_FETCH_CODES(g + 2 * kWsNW + wid);                   // the group after the next
     }
+#undef WS_FETCH_STATE
+#undef WS_PUBLISH
 #undef WS_FETCH_TABLE
 #undef WS_FETCH_CODES
   }

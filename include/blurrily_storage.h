@@ -159,6 +159,11 @@ typedef struct blurrily_device_info_t {
   uint32_t n_pending;           /* puts since the base image was built (served by a delta image) */
   uint32_t n_tombstones;        /* base references deleted since the build                       */
   uint64_t base_builds;         /* full device-image builds so far                               */
+  double   mean_hit_slice;      /* postings a needle trigram finds per window, on average: what the
+                                   choice between the two sweeps is gated on ("ws_min_slice")     */
+  uint32_t n_bitmaps;           /* dense slices that also exist as bitmaps (0: the window-major
+                                   sweep cannot run on this image)                               */
+  uint32_t reserved_;
 } blurrily_device_info_t;
 int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* info);
 

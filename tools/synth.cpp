@@ -148,8 +148,14 @@ uint64_t synth_geonames(uint64_t seed, uint32_t n, uint32_t vocab, char* out, ui
   return pos;
 }
 
-// configs[4]: heavy bucket skew and massive (matches, weight) ties.
+// configs[4]: heavy bucket skew and massive (matches, weight) ties.  `hot_pct` (synth_skewed: 100) scales how
+// often a string takes one of the hot prefixes / suffixes -- 0 leaves the bare stems -- which moves the haystack's
+// mean posting-list size per window between a plain and a hot-trigram one (tools/gate_probe.py).
+uint64_t synth_skewed_mix(uint64_t seed, uint32_t n, uint32_t hot_pct, char* out, uint64_t* offsets);
 uint64_t synth_skewed(uint64_t seed, uint32_t n, char* out, uint64_t* offsets) {
+  return synth_skewed_mix(seed, n, 100, out, offsets);
+}
+uint64_t synth_skewed_mix(uint64_t seed, uint32_t n, uint32_t hot_pct, char* out, uint64_t* offsets) {
   Rng r(seed);
   static const char* kPre[] = {"san ", "new ", "saint ", "el ", "la "};
   static const char* kSuf[] = {"ville", " city", "ton", "burg"};
@@ -158,11 +164,18 @@ uint64_t synth_skewed(uint64_t seed, uint32_t n, char* out, uint64_t* offsets) {
   for (uint32_t i = 0; i < n; ++i) {
     offsets[i] = pos;
     const uint32_t x = r.below(100);
-    if (x < 70) { const char* p = kPre[r.below(x < 45 ? 2 : 5)]; const size_t l = std::strlen(p); std::memcpy(out + pos, p, l); pos += l; }
+    if (x < 70) {                                                  // (the draws are hot_pct-independent: one stream of strings)
+      const uint32_t pick_pre = r.below(x < 45 ? 2 : 5);
+      if (x * 100 < 70 * hot_pct) { const char* p = kPre[pick_pre]; const size_t l = std::strlen(p); std::memcpy(out + pos, p, l); pos += l; }
+    }
     const std::string& w = stems[r.below(uint32_t(stems.size()))];
     std::memcpy(out + pos, w.data(), w.size());
     pos += w.size();
-    if (r.below(100) < 60) { const char* s = kSuf[r.below(r.below(100) < 70 ? 1 : 4)]; const size_t l = std::strlen(s); std::memcpy(out + pos, s, l); pos += l; }
+    const uint32_t y = r.below(100);
+    if (y < 60) {
+      const uint32_t pick_suf = r.below(r.below(100) < 70 ? 1 : 4);
+      if (y * 100 < 60 * hot_pct) { const char* s = kSuf[pick_suf]; const size_t l = std::strlen(s); std::memcpy(out + pos, s, l); pos += l; }
+    }
   }
   offsets[n] = pos;
   return pos;

@@ -25,6 +25,7 @@ def _synth():
             "synth_words": [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
             "synth_geonames": [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
             "synth_skewed": [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
+            "synth_skewed_mix": [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
             "synth_queries": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p],
             "synth_count_trigrams": [C.c_void_p, C.c_void_p, C.c_uint32],
         }.items():
@@ -56,6 +57,12 @@ def geonames(n=8423769, vocab=500000, seed=3):
 def skewed(n=4000000, seed=5):
     """configs[4]: hot-trigram haystack with massive (matches, weight) ties."""
     return _run(n, lambda L, b, o: L.synth_skewed(seed, n, b, o))
+
+
+def skewed_mix(n=4000000, hot_pct=100, seed=5):
+    """The skewed haystack with its hot prefixes / suffixes on `hot_pct` per cent of the strings that would take
+    them (100: `skewed`; 0: bare stems): haystacks between plain and hot-trigram (tools/gate_probe.py)."""
+    return _run(n, lambda L, b, o: L.synth_skewed_mix(seed, n, hot_pct, b, o))
 
 
 def queries(hay, hay_off, n, seed):
