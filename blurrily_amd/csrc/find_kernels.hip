@@ -1110,13 +1110,14 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // test before the atomics.  A unit's address is a scalar base (its first entry) plus the lane's 16 bytes:
   // nothing per unit and lane but the load itself and one compare.  (Up to four of a wave's units loaded before
   // the first is counted -- four loads in flight -- measured in round 3: 3.2 % SLOWER, 317.2 vs 307.4 ms.)
-#define BLURRILY_COUNT_UNITS(s_, n_)                                             \
+#define BLURRILY_COUNT_UNITS(s_, n_, have_first_)                                \
   do {                                                                           \
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
     uint32_t pend_h_ = 0;                                                        \
     bool pend_live_ = false;                                                     \
     for (uint32_t k_ = wid; k_ < (n_); k_ += kNW) {                              \
-      const uint2 d_ = ring->desc[s_][k_];                                       \
+      uint2 d_ = d_first;                       /* (the wave's first unit: read a step ago, behind the count barrier) */ \
+      if (!(have_first_) || k_ != wid) d_ = ring->desc[s_][k_];                  \
       const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                  \
       const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                  \
       const uint32_t x0_ = x_ & ~7u;                                             \
@@ -1192,6 +1193,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   bool have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
   const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
   __syncthreads();
+  uint2 h_next = ring->hdr[0];                                   // header of the step about to start ...
+  uint2 d_first = ring->desc[0][wid];                            // ... and this wave's first unit of it
 
   // The sweep is a HOT LOOP of steps that need nothing special -- header, units, turns, barrier, scan with the
   // published bound, barrier, a glance at the pool -- and is left for everything else (more units than the ring
@@ -1203,9 +1206,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     uint32_t left, s, p, n_units;
     for (;; ++e) {
       s = e & 1;
-      const uint2 h_ = ring->hdr[s];
-      p = __builtin_amdgcn_readfirstlane(h_.x);
-      const uint32_t hy_ = __builtin_amdgcn_readfirstlane(h_.y);
+      p = __builtin_amdgcn_readfirstlane(h_next.x);
+      const uint32_t hy_ = __builtin_amdgcn_readfirstlane(h_next.y);
       n_units = hy_ & 0xFFFFu;
       if (p >= v1) { left = kLeftDone; break; }                 // no step left
       ++st_steps;
@@ -1214,11 +1216,16 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // issue ahead of the others from the start of the step)
       if (wid == BLURRILY_PRODUCER(e + 1) || wid == BLURRILY_PRODUCER(e + 2)) __builtin_amdgcn_s_setprio(2);
       if (n_units == kRingWalk) { left = kLeftWalk; break; }
-      BLURRILY_COUNT_UNITS(s, n_units);
+      BLURRILY_COUNT_UNITS(s, n_units, true);
       PHASE_MARK(2);                                            // units counted
       BLURRILY_TAKE_TURNS(e, s);
       __syncthreads();                                          // counts and next descriptors visible
       PHASE_MARK(3);                                            // barrier after count
+      // The next step's header and this wave's first unit of it were published before that barrier: requested now,
+      // they arrive under the scan instead of standing, one LDS round trip each (several hundred clocks behind the
+      // other workgroup's atomics), between the scan barrier and the first load of the next step.
+      h_next = ring->hdr[s ^ 1u];
+      d_first = ring->desc[s ^ 1u][wid];
       if (n_units == 0) continue;                               // nothing of the needle in this step's windows
       const uint32_t need = hy_ >> 16;
       if (need == 0) { left = kLeftSlowScan; break; }
@@ -1254,11 +1261,13 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
       ++st_redo;                                                // pool overflow: sweep step p again
       if (n_units == kRingWalk) BLURRILY_COUNT_WALK(p);
-      else BLURRILY_COUNT_UNITS(s, n_units);
+      else BLURRILY_COUNT_UNITS(s, n_units, false);
       __syncthreads();
     }
     have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
     ++e;
+    h_next = ring->hdr[e & 1];                                  // (published behind step p's count barrier)
+    d_first = ring->desc[e & 1][wid];
   }
   PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
@@ -1400,20 +1409,35 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
       else                    sweep_chunked<CT, NT>(A, nd, codes, cnt32, pool, s_tab, ctl, sa, sb);     \
     }                                                                                                   \
   } while (0)
+    uint32_t sw_a = 0, sw_b = 0, sw_st = 0;
+    (void)sw_a; (void)sw_b; (void)sw_st;
+#define BLURRILY_SWEEP_ARGS(a_, b_, st_) do { sw_a = (a_); sw_b = (b_); sw_st = (st_); } while (0)
     if constexpr (RANGED) {
       // A range that does not contain the needle's own length class first sweeps that window
       // only to learn a threshold (the keep-th best of real candidates bounds the answer), then
       // forgets those candidates -- the range that owns the window reports them -- and sweeps
       // its own windows with few admissions instead of a cold start.  (It pays even for a range
       // of one step: without it a single needle takes 88 us instead of 81.)
-      if (qs < A.n_windows && !(qs >= w0 && qs < w1)) {
-        BLURRILY_SWEEP(qs, qs + 1, qs);
-        compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
-        if (tid == 0) ctl->pool_n = 0;
-        __syncthreads();
+      // (ONE expansion of the sweep serves both: two of them -- four inlined sweeps -- cost the latency-mode
+      // kernel 380 spilled registers)
+      const bool learn = qs < A.n_windows && !(qs >= w0 && qs < w1);
+      for (uint32_t pass = learn ? 0u : 1u; pass < 2u; ++pass) {
+        if (pass == 0) {
+          BLURRILY_SWEEP_ARGS(qs, qs + 1, qs);
+        } else {
+          BLURRILY_SWEEP_ARGS(w0, w1, ws);
+        }
+        BLURRILY_SWEEP(sw_a, sw_b, sw_st);
+        if (pass == 0) {
+          compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+          if (tid == 0) ctl->pool_n = 0;
+          __syncthreads();
+        }
       }
+    } else {
+      BLURRILY_SWEEP(w0, w1, ws);
     }
-    BLURRILY_SWEEP(w0, w1, ws);
+#undef BLURRILY_SWEEP_ARGS
 #undef BLURRILY_SWEEP
     PHASE_NEEDLE(11);
 
