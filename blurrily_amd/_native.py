@@ -30,6 +30,7 @@ class DeviceInfo(C.Structure):
         ("last_find_kernel_ms", C.c_double), ("last_tokenise_kernel_ms", C.c_double),
         ("n_pending", C.c_uint32), ("n_tombstones", C.c_uint32), ("base_builds", C.c_uint64),
         ("mean_hit_slice", C.c_double), ("n_bitmaps", C.c_uint32), ("reserved_", C.c_uint32),
+        ("dense_share", C.c_double), ("ws_gain", C.c_double),
     ]
 
 

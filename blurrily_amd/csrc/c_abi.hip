@@ -345,10 +345,16 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // Large batches over many windows: the window-major sweep (find_kernels.hip, wsweep_kernel).
     // Phase 1 -- the needle-major kernel over the window pair of every needle's own length class --
     // seeds the needles' states; one launch per window follows; keys become rows at the end.
-    // (which images it runs on -- enough windows, slices big enough to pay a task's fixed cost back --
-    // is IndexBuildOptions::wants_bitmaps: an image it cannot run on carries no bitmaps)
+    // Which images it runs on at all -- enough windows, slices big enough -- is IndexBuildOptions::wants_bitmaps
+    // (an image it cannot run on carries no bitmaps).  How big the slices must be depends on the batch and the
+    // limit: measured (tools/gate_probe.py, table in DESIGN.md section 5: both sweeps on haystacks from plain to
+    // hot-trigram, 16 k .. 1 M needles, limits 10 and 100) the two sweeps break even at mean_hit_slice ~1700 for
+    // batches of 65 536 needles or more at limit 10, ~3500 for smaller batches or for limit 100, and a small
+    // batch at limit 100 loses even at 8500; the gate sits above the break-even (1.1x or better where taken).
+    const double slice_factor = (n < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
     const bool use_ws = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.d_bm_id != nullptr &&
-                        m->build_opt.wants_bitmaps(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
+                        m->build_opt.wants_bitmaps(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull &&
+                        ix.mean_hit_slice >= slice_factor * double(m->build_opt.ws_min_slice);
     if (use_ws) {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
@@ -818,6 +824,8 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
   info->mean_hit_slice = m->dev.mean_hit_slice;
   info->n_bitmaps = m->dev.d_bm_id ? m->dev.n_bitmaps : 0;
   info->reserved_ = 0;
+  info->dense_share = m->dev.dense_share;
+  info->ws_gain = m->dev.ws_gain;
   return 0;
 }
 

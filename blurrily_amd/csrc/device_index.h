@@ -82,6 +82,13 @@ struct DeviceIndex {
   // sweep pays a fixed price per (needle, window) and saves in proportion to the postings it leaves
   // out, so it is taken only where slices are big (c_abi.hip).
   double    mean_hit_slice   = 0.0;
+  // share of those postings that sit in slices of at least dense_min postings -- the ones the window-major sweep
+  // can leave out of the count: sum of len^2 over dense (window, code) slices / over all slices
+  double    dense_share      = 0.0;
+  // the part of mean_hit_slice that comes from the haystack's four biggest buckets x postings per reference:
+  // the postings a needle as long as the haystack's strings can expect to LEAVE OUT per window -- what the
+  // window-major sweep's fixed price per (needle, window) is paid from (measured table in DESIGN.md section 5)
+  double    ws_gain          = 0.0;
   // host copies for mapping a reference to its rank (deletes after the build)
   std::vector<uint32_t> h_sorted_ref;     // references ascending
   std::vector<uint32_t> h_rank_of_pos;    // rank of h_sorted_ref[i]
@@ -93,7 +100,8 @@ struct DeviceIndex {
 struct IndexBuildOptions {
   bool     ws_enabled     = true;
   uint32_t ws_min_windows = 8;      // fewer windows: the needle-major sweep is taken whatever the batch
-  uint32_t ws_min_slice   = 3000;   // least DeviceIndex::mean_hit_slice (measured gate)
+  uint32_t ws_min_slice   = 2200;   // least DeviceIndex::mean_hit_slice for the most favourable batches (measured
+                                    // gate; c_abi.hip raises it for small batches / large limits)
   uint32_t dense_min      = kDenseMin;
   bool wants_bitmaps(uint32_t n_windows, double mean_hit_slice) const {
     return ws_enabled && n_windows >= ws_min_windows && mean_hit_slice >= double(ws_min_slice);

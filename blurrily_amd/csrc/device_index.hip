@@ -290,8 +290,32 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
     for (uint32_t t = 0; t < kNumCodes; ++t) sq += double(code_total[t]) * double(code_total[t]);
     mean_hit_slice = nnz ? sq / double(nnz) / double(n_win) : 0.0;
   }
-  const bool with_bitmaps = opt.wants_bitmaps(n_win, mean_hit_slice);
   const uint32_t dense_min = std::max(64u, opt.dense_min);
+  double dense_share = 0.0;
+  {
+    double all = 0.0, dense = 0.0;                             // (slice_off[i + 1] still holds slice i's length here)
+    for (uint64_t i = 0; i < n_slices; ++i) {
+      const double len = double(slice_off[i + 1]);
+      all += len * len;
+      if (slice_off[i + 1] >= dense_min) dense += len * len;
+    }
+    dense_share = all > 0.0 ? dense / all : 0.0;
+  }
+  // What the window-major sweep can save: it leaves out the few LARGEST dense slices of a needle (at most
+  // need - cmin of them, a handful), so what counts is how much of a needle's postings sits in the haystack's few
+  // hottest trigrams -- mean_hit_slice minus the same figure without the kHotCodes biggest buckets -- times the
+  // trigrams a needle as long as the haystack's strings has.  (A haystack whose postings are spread over
+  // hundreds of middling buckets -- Geonames scale -- has a high mean_hit_slice and little to leave out.)
+  double ws_gain = 0.0;
+  if (nnz && n_refs) {
+    constexpr size_t kHotCodes = 4;
+    std::vector<uint32_t> top(code_total.begin(), code_total.end());
+    std::partial_sort(top.begin(), top.begin() + kHotCodes, top.end(), std::greater<uint32_t>());
+    double hot_sq = 0.0;
+    for (size_t i = 0; i < kHotCodes; ++i) hot_sq += double(top[i]) * double(top[i]);
+    ws_gain = hot_sq / double(nnz) / double(n_win) * (double(nnz) / double(n_refs));
+  }
+  const bool with_bitmaps = opt.wants_bitmaps(n_win, mean_hit_slice);
   std::vector<uint32_t> bm_id(with_bitmaps ? n_slices : 0, kNoBitmap);
   uint32_t n_bitmaps = 0;
   for (uint64_t i = 0; i < n_slices; ++i) {
@@ -423,6 +447,8 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   ix.built_from = host.generation();
   ix.n_bitmaps = n_bitmaps;
   ix.mean_hit_slice = mean_hit_slice;
+  ix.dense_share = dense_share;
+  ix.ws_gain = ws_gain;
   while (ix.nib_windows + 1 < n_win && win_max_tri[ix.nib_windows] <= 15 && win_max_tri[ix.nib_windows + 1] <= 15)
     ix.nib_windows += 2;
   auto up = [&](auto** dptr, const auto& v, size_t min_elems) -> int {   // v may be a temporary

@@ -164,6 +164,9 @@ typedef struct blurrily_device_info_t {
   uint32_t n_bitmaps;           /* dense slices that also exist as bitmaps (0: the window-major
                                    sweep cannot run on this image)                               */
   uint32_t reserved_;
+  double   dense_share;         /* share of those postings in slices dense enough to have a bitmap  */
+  double   ws_gain;             /* the four biggest buckets' part of mean_hit_slice x postings per
+                                   reference: postings a needle can expect to leave out per window */
 } blurrily_device_info_t;
 int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* info);
 
@@ -194,7 +197,8 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  * Per map -- read by the map's next find; calls on one map are serial, as in the reference:
  *   "wsweep"          1 (default) / 0: whether the window-major sweep may be taken at all
  *   "ws_min_windows"  (8)     fewest windows of an image it is taken on
- *   "ws_min_slice"    (3000)  least mean postings a needle trigram finds per window (measured gate)
+ *   "ws_min_slice"    (2200)  least mean postings a needle trigram finds per window (measured gate, DESIGN.md;
+ *                             x1.7 for batches under 65 536 needles, x1.7 for limits above 32, x4 for both)
  *   "ws_min_needles"  (16384) smallest batch it is taken for
  *   "ws_cmin"         (3)     counted matches a left-out slice must leave
  *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing

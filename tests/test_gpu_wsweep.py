@@ -166,3 +166,58 @@ def test_randomised_window_major_configurations(seed):
     for ref in rng.choice(refs, size=200, replace=False):       # tombstones on the base image
         assert m.delete(int(ref)) == o.delete(int(ref))
     _check_all(m, o, q, qo, limit)
+
+
+@pytest.mark.parametrize("hot_pct", [0, 25, 50, 75, 100])
+def test_both_sweeps_agree_along_the_gate(hot_pct):
+    """The haystacks the sweep-choice gate was measured on (tools/gate_probe.py: the skewed generator with its hot
+    prefixes / suffixes on 0 .. 100 per cent of the strings; mean_hit_slice from plain to hot-trigram), smaller:
+    whichever sweep the gate picks, the rows are the same -- window-major against needle-major, row for row, and a
+    sample against the oracle."""
+    hay, off = W.skewed_mix(600000, hot_pct, 81)                # 10 windows
+    m, o = _pair(hay, off)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000)
+    q, qo = W.queries(hay, off, 12000, 82)
+    for limit in (10, 100):
+        m.set_option("wsweep", 1)
+        m.set_stats(True)
+        a_rows, a_counts = m.find_batch_packed(q, qo, limit)
+        assert m.find_stats()["probes"] > 0 or hot_pct == 0       # (bare stems: hardly a dense slice to leave out)
+        m.set_stats(False)
+        m.set_option("wsweep", 0)
+        b_rows, b_counts = m.find_batch_packed(q, qo, limit)
+        assert np.array_equal(a_counts, b_counts)
+        live = np.arange(limit)[None, :] < a_counts[:, None].astype(np.int64)
+        assert np.array_equal(np.where(live[:, :, None], a_rows, 0), np.where(live[:, :, None], b_rows, 0))
+    idx = np.arange(0, 12000, 12, dtype=np.uint32)
+    want = o.batch(q, qo, idx=idx, limit=100)
+    assert np.array_equal(b_counts[idx], want["counts"])
+    live = np.arange(100)[None, :] < want["counts"][:, None].astype(np.int64)
+    assert np.array_equal(np.where(live[:, :, None], b_rows[idx], 0), np.where(live[:, :, None], want["rows"], 0))
+    info = m.device_info()
+    assert info["n_bitmaps"] > 0 and info["mean_hit_slice"] > 0
+
+
+def test_the_default_gate_follows_the_measured_table():
+    """Without any option set: the sweep is chosen by the image's mean_hit_slice against 2200 (x1.7 for a batch under
+    65 536 needles, x1.7 for a limit above 32, x4 for both), for batches of 16 384 needles or more over 8 windows
+    or more -- the rule DESIGN.md section 5 derives from tools/gate_probe.py's table.  An image the sweep can never
+    run on carries no bitmaps."""
+    for gen, kw in ((W.skewed, dict(n=600000, seed=45)), (W.geonames, dict(n=600000, vocab=80000, seed=41))):
+        hay, off = gen(**kw)
+        m = RawMap()
+        m.put_many_packed(hay, off, np.arange(1, len(off), dtype=np.uint32))
+        m.sync_device()
+        info = m.device_info()
+        mhs = info["mean_hit_slice"]
+        assert (info["n_bitmaps"] > 0) == (mhs >= 2200 and info["n_windows"] >= 8), info
+        for n_q, limit in ((70000, 10), (20000, 10), (70000, 100), (20000, 100), (8000, 10)):
+            factor = (4.0 if limit > 32 else 1.7) if n_q < 65536 else (1.7 if limit > 32 else 1.0)
+            expect_ws = n_q >= 16384 and info["n_windows"] >= 8 and mhs >= factor * 2200
+            q, qo = W.queries(hay, off, n_q, 90)
+            m.set_stats(True)
+            m.find_batch_packed(q, qo, limit)
+            took_ws = m.find_stats()["probes"] > 0
+            m.set_stats(False)
+            assert took_ws == expect_ws, (gen.__name__, mhs, n_q, limit, took_ws)
+        m.close()

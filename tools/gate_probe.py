@@ -23,12 +23,15 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
     batches = [int(a) for a in sys.argv[2:]] or [16384, 100_000, 1_000_000]
     limit = int(os.environ.get("GATE_LIMIT", "10"))
-    points = [("skew %d%%" % p, lambda p=p: W.skewed_mix(n, p, 5)) for p in (0, 25, 50, 75, 100)]
+    pcts = [int(x) for x in os.environ.get("GATE_PCTS", "0,25,50,75,100").split(",")]
+    points = [("skew %d%%" % p, lambda p=p: W.skewed_mix(n, p, 5)) for p in pcts]
     if os.environ.get("GATE_GEONAMES", "1") != "0":
         points.append(("geonames", lambda: W.bench_haystack("geonames")))
-    print(f"| haystack | strings | windows | mean_hit_slice | " +
+        points.append(("geonames 1/2", lambda: W.bench_haystack("geonames", 0.5)))
+        points.append(("words 4M", lambda: W.words(4_000_000, 9)))
+    print(f"| haystack | strings | windows | mean_hit_slice | dense_share | ws_gain | " +
           " | ".join(f"{b} needles: needle-major / window-major ms (ratio)" for b in batches) + " |")
-    print("|---|---|---|---|" + "---|" * len(batches))
+    print("|---|---|---|---|---|---|" + "---|" * len(batches))
     for label, gen in points:
         hay, off = gen()
         m = RawMap()
@@ -54,9 +57,11 @@ def main():
                         np.array_equal(np.where(live[:, :, None], a[1], 0), np.where(live[:, :, None], b[1], 0)))
             cells.append(f"{a[0]:.1f} / {b[0]:.1f} ({a[0] / b[0]:.2f}x){'' if same else ' ROWS DIFFER'}")
             print(json.dumps({"haystack": label, "strings": len(off) - 1, "windows": info["n_windows"],
-                              "mean_hit_slice": info["mean_hit_slice"], "needles": nq, "limit": limit,
+                              "mean_hit_slice": info["mean_hit_slice"], "dense_share": info["dense_share"],
+                              "ws_gain": info["ws_gain"], "needles": nq, "limit": limit,
                               "needle_major_ms": a[0], "window_major_ms": b[0], "rows_equal": same}), file=sys.stderr)
-        print(f"| {label} | {len(off) - 1} | {info['n_windows']} | {info['mean_hit_slice']:.0f} | " + " | ".join(cells) + " |",
+        print(f"| {label} | {len(off) - 1} | {info['n_windows']} | {info['mean_hit_slice']:.0f} | {info['dense_share']:.2f} | "
+              f"{info['ws_gain']:.0f} | " + " | ".join(cells) + " |",
               flush=True)
         m.close()
 
