@@ -6,14 +6,17 @@
 #   stats_skewed/                      the same for --workload skewed (the window-major sweep's kernels)
 #   pmc_{fetch,write,tcc}_<workload>/  rocprofv3 --pmc passes, one counter group per run, per workload
 #   traffic.json                       tools/traffic_summary.py over those passes
-tag=${1:-r02}
+# (PROFILE_COMMIT=<short hash> in the environment stamps traffic.json: the GPU box has no .git)
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python $root/bench.py > $out/bench.json 2> $out/bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra > $out/stats_bench.json 2> $out/stats_bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline > $out/stats_skewed.json 2> $out/stats_skewed.log
+# (--latency-probes 0: no single finds, no host-buffer batch -- whose chunks are launches of the same kernel --
+#  so that the kernel's average duration in the summary is the timed steps' and the warm-up's)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra --latency-probes 0 > $out/stats_bench.json 2> $out/stats_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline --latency-probes 0 > $out/stats_skewed.json 2> $out/stats_skewed.log
 for wl in geonames words skewed; do
   for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
     name=${pass%%:*}; ctrs=${pass#*:}

@@ -36,9 +36,23 @@ def totals(dirpath):
     return {"sum": out, "per_kernel": per_kernel}
 
 
+def kernel_source_hash():
+    """bench.py's: sha256 over the kernel and launch sources this profile was taken at."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("find_kernels.hip", "find_kernels.h", "device_index.hip", "device_index.h", "c_abi.hip"):
+        with open(os.path.join(root, "blurrily_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     base = sys.argv[1]
-    out = {"_how": " ".join(__doc__.split("\n\n")[1].split())}
+    out = {"_how": " ".join(__doc__.split("\n\n")[1].split()),
+           # what bench.py checks the figure's freshness against (the GPU box has no .git: the commit comes from
+           # the caller, PROFILE_COMMIT=$(git rev-parse --short HEAD) in the gpurun command line)
+           "kernel_source_hash": kernel_source_hash(), "commit": os.environ.get("PROFILE_COMMIT")}
     detail = {}
     for wl in ("geonames", "words", "skewed"):
         d = {}
