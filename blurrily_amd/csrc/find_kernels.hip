@@ -1652,15 +1652,28 @@ __device__ __forceinline__ unsigned long long ws_load_key(const FindArgs& A, uin
   return (static_cast<unsigned long long>(st[2 * i + 1]) << 32) | st[2 * i];
 }
 
-// One posting into the single-window 4-bit layout.  The index deals the postings of a unit so that one
+// The single-window 4-bit layout.  The index deals the postings of a unit so that one
 // LDS instruction sees each BYTE-counter bank once (bank = (r >> 2) & 31, device_index.hip); the 4-bit
 // layout keeps that bank: rank r -> word (r >> 2) & 0x1FFF, i.e. byte address r & 0x7FFC, and nibble
 // (r & 3) | (r >> 15) << 2 -- a word holds ranks 4w..4w+3 of the window's lower half in its low nibbles
 // and ranks 32768 + 4w.. of the upper half in its high ones.  (With word = r >> 3, 61 % of the LDS-active
 // cycles were bank conflicts, profiles/r02_ws_pmc.txt.)
-__device__ __forceinline__ void ws_bump_nib(uint32_t* cnt32, uint32_t r) {
-  const uint32_t sh = ((r & 3u) << 2) | ((r >> 11) & 16u);
-  __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cnt32) + (r & 0x7FFCu)), 1u << sh,
+// Both ranks of a packed dword into that layout, 5 + 6 VALU instead of 8 + 8: the shift amount is built so that
+// its junk sits above bit 4, which the shifter does not read (v_lshlrev_b32 takes five bits of the amount).
+//   low half  r = v & 0xFFFF:  x = v & 0x8003 keeps r's bits 1:0 and 15;  (x << 2) + (x >> 11) = 4 (r & 3) + 16 (r >> 15) + 2^17 (r >> 15)
+//   high half r = v >> 16:     y = v & 0x80030000;  (y >> 14) | (y >> 27) = 4 (r & 3) + 16 (r >> 15) + 2^17 (r >> 15)
+__device__ __forceinline__ uint32_t one_shl_low5(uint32_t amount) {
+  uint32_t out;
+  asm("v_lshlrev_b32 %0, %1, 1" : "=v"(out) : "v"(amount));
+  return out;
+}
+__device__ __forceinline__ void ws_bump_pair_nib(uint32_t* cnt32, uint32_t v) {
+  unsigned char* const base = reinterpret_cast<unsigned char*>(cnt32);
+  const uint32_t x = v & 0x8003u;
+  __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + (v & 0x7FFCu)), one_shl_low5((x << 2) + (x >> 11)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t y = v & 0x80030000u;
+  __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + ((v >> 16) & 0x7FFCu)), one_shl_low5((y >> 14) | (y >> 27)),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // one posting into the half-window byte layout: rank r of half `h` -> byte r & 0x7FFF; a posting of the
@@ -1676,7 +1689,7 @@ __device__ __forceinline__ void ws_bump8(uint32_t* cnt32, const uint4 v, uint32_
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (WIDE) { ws_bump_byte(cnt32, d[j] & 0xFFFFu, h); ws_bump_byte(cnt32, d[j] >> 16, h); }
-    else      { ws_bump_nib(cnt32, d[j] & 0xFFFFu);     ws_bump_nib(cnt32, d[j] >> 16); }
+    else      { ws_bump_pair_nib(cnt32, d[j]); }
   }
 }
 
@@ -1723,7 +1736,7 @@ __device__ __forceinline__ void ws_compact_pool(unsigned long long* pool, Contro
 
 // What the scans need to know about the two counter layouts of wsweep_kernel.
 //   WIDE = false: 4-bit counters, the whole window: word w holds ranks 4w..4w+3 (nibbles 0..3) and
-//                 32768 + 4w.. (nibbles 4..7), see ws_bump_nib; vector i = words 4i..4i+3
+//                 32768 + 4w.. (nibbles 4..7), see ws_bump_pair_nib; vector i = words 4i..4i+3
 //   WIDE = true : byte counters of half h of the window: vector i holds ranks [32768 h + 16 i, ... + 16)
 template <bool WIDE> struct WsLayout {
   static constexpr uint32_t kRanksPerVec = WIDE ? 16 : 32, kBits = WIDE ? 8 : 4, kPerWord = WIDE ? 4 : 8;
