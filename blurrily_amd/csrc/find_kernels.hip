@@ -2026,12 +2026,13 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
       if (STATS(A) && my_ti < n_tasks) { st_tab += 3 * my_T; ++st_tasks; }
       // Every wave publishes the first pass of its own task now, the four of them side by side -- from what the
       // filter learnt of the needle (its threshold's bound, whether it has one) -- instead of one after the other
-      // with the other three waves waiting at a barrier (a fifth of a task's time, profiles/r03: "skipsel").  The
-      // barrier behind the first task's state makes all four visible.
+      // with the other three waves waiting at a barrier (a fifth of a task's time, profiles/r03: "skipsel").  One
+      // barrier per group makes all four visible.
       if (my_ti < n_tasks) {
         const uint32_t meta_ = s_task_meta[my_ti];
         WS_PUBLISH(wid, my_T, meta_ >> 16, ((meta_ >> 8) & 0xFFu) < keep);
       }
+      ws_barrier();
 
       for (uint32_t j = 0; j < kWsNW && g + j < n_tasks; ++j) {
         const uint32_t ti = g + j;
@@ -2045,16 +2046,18 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
         if (tid < cnt0) s_pool[tid] = my_key;
         if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
         if (tid == keep - 1 || (tid == 0 && cnt0 < keep)) ctl->thr = cnt0 >= keep ? my_key : kKeyInf;
-        ws_barrier();
+        // (no barrier: nothing of the state is read before the first pass's count barrier -- the bound and the pool's
+        // size come from what the filter noted of the needle, the threshold is read behind that barrier)
         bool changed = false, first_pass = true;
         bool robust = cnt0 < keep;                           // no threshold yet: nothing can be left out
         PATH_FLAG(A, q, robust ? kPathWsTask | kPathWsRobust : kPathWsTask);
         WS_CLOCK(1);
 
         for (;;) {                                           // again after an overflow (rare)
-          const unsigned long long thr = ctl->thr;
-          const uint32_t pool_at_start = ctl->pool_n;
-          const uint32_t need = matches_needed(thr, T, wbase);
+          unsigned long long thr = kKeyInf;
+          uint32_t pool_at_start = cnt0, need = meta >> 16;
+          if (!first_pass) { thr = ctl->thr; pool_at_start = ctl->pool_n; need = matches_needed(thr, T, wbase); }
+          const bool was_first = first_pass;
           if (min(T, wmt) < need) break;                     // (the threshold tightened in an earlier pass)
           // (the first pass was published when the group began; a later one -- the threshold tightened, or the robust
           // way after an overflow -- by the owner now)
@@ -2107,6 +2110,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
             WS_CLOCK(7);                                     // units loaded and counted
             ws_barrier();
             WS_CLOCK(2);                                     // barrier after the count
+            if (was_first && h == 0) thr = ctl->thr;         // (the task's state is visible from here on)
             // ---- scan: counters that reach need_eff become candidates; everything is cleared -------
             if (!robust) {
               if (wide) ws_scan_fast<true>(cnt128, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov, need_eff, h, wlen);
