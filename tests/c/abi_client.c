@@ -49,6 +49,20 @@ int main(int argc, char** argv) {
     }
   }
 
+  /* tunables go through the ABI (nothing reads the environment): per map, and process-wide with a NULL map */
+  {
+    long long v = -1;
+    CHECK(blurrily_storage_get_option(map, "ws_min_slice", &v) == 0 && v == 2200);
+    CHECK(blurrily_storage_set_option(map, "wsweep", 0) == 0);
+    CHECK(blurrily_storage_get_option(map, "wsweep", &v) == 0 && v == 0);
+    errno = 0;
+    CHECK(blurrily_storage_set_option(map, "no_such_option", 1) == -1 && errno == EINVAL);
+    CHECK(blurrily_storage_set_option(NULL, "host_threads", 2) == 0);
+    CHECK(blurrily_storage_get_option(NULL, "host_threads", &v) == 0 && v == 2);
+    CHECK(blurrily_storage_set_option(NULL, "host_threads", 0) == 0);
+    if (gpu) CHECK(blurrily_storage_find(map, "london", 10, rows) == 2);      /* same rows whatever the options */
+  }
+
   CHECK(blurrily_storage_delete(map, 11) == 8);
   CHECK(blurrily_storage_save(map, path) == 0);
   CHECK(blurrily_storage_close(&map) == 0 && map == NULL);
