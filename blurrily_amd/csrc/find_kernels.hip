@@ -1676,6 +1676,43 @@ __device__ __forceinline__ void ws_bump_pair_nib(uint32_t* cnt32, uint32_t v) {
   __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + ((v >> 16) & 0x7FFCu)), one_shl_low5((y >> 14) | (y >> 27)),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// The same with the counter's value BEFORE the increment coming back: a counter that was at need - 1 has just
+// reached `need` -- its rank goes to the candidate list at once (a counter crosses a value exactly once: a slice
+// holds a reference once, counts only grow), so that the window's counters need not be SCANNED for candidates
+// afterwards, only cleared.  (v_bfe_u32 reads five bits of its offset, like the shifter: the same junk-tolerant
+// amounts serve.)  Padding (rank 0xFFFF) and ranks past the window's end never become candidates.
+__device__ __forceinline__ uint32_t bfe4_low5(uint32_t value, uint32_t offset) {
+  uint32_t out;
+  asm("v_bfe_u32 %0, %1, %2, 4" : "=v"(out) : "v"(value), "v"(offset));
+  return out;
+}
+__device__ __forceinline__ void ws_push_cand(uint32_t* cand, uint32_t* n_cand, uint32_t* cand_ov, uint32_t r16) {
+  const uint32_t at = atomicAdd(n_cand, 1u);
+  if (at < kWsCand) cand[at] = r16; else *cand_ov = 1;
+}
+__device__ __forceinline__ void ws_bump8_cross(uint32_t* cnt32, const uint4 v, uint32_t need, uint32_t wlen,
+                                               uint32_t* cand, uint32_t* n_cand, uint32_t* cand_ov) {
+  if (!group_live(v)) return;
+  unsigned char* const base = reinterpret_cast<unsigned char*>(cnt32);
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+  uint32_t old_lo[4], old_hi[4], sh_lo[4], sh_hi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                              // eight returning atomics in flight
+    const uint32_t x = d[j] & 0x8003u, y = d[j] & 0x80030000u;
+    sh_lo[j] = (x << 2) + (x >> 11);
+    sh_hi[j] = (y >> 14) | (y >> 27);
+    old_lo[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + (d[j] & 0x7FFCu)), one_shl_low5(sh_lo[j]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old_hi[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + ((d[j] >> 16) & 0x7FFCu)), one_shl_low5(sh_hi[j]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  const uint32_t was = need - 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (bfe4_low5(old_lo[j], sh_lo[j]) == was && (d[j] & 0xFFFFu) < wlen) ws_push_cand(cand, n_cand, cand_ov, d[j] & 0xFFFFu);
+    if (bfe4_low5(old_hi[j], sh_hi[j]) == was && (d[j] >> 16) < wlen) ws_push_cand(cand, n_cand, cand_ov, d[j] >> 16);
+  }
+}
 // one posting into the half-window byte layout: rank r of half `h` -> byte r & 0x7FFF; a posting of the
 // other half goes to a dump word behind the counters
 __device__ __forceinline__ void ws_bump_byte(uint32_t* cnt32, uint32_t r, uint32_t h) {
@@ -1918,7 +1955,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
   unsigned long long ws_clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_last = clock64();
 
   for (;;) {
-    if (tid == 0) { s_ctl.chunk = atomicAdd(A.queue, 1u); s_ctl.n_tasks = 0; }
+    if (tid == 0) { s_ctl.chunk = atomicAdd(A.queue, 1u); s_ctl.n_tasks = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
     ws_barrier();
     const uint32_t base = s_ctl.chunk * chunk_len;           // chunk_len <= kWsNT needles per queue pop
     if (base >= n) break;
@@ -2044,7 +2081,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
         const unsigned long long my_key = pf_key;
         WS_FETCH_STATE(ti + 1);
         if (tid < cnt0) s_pool[tid] = my_key;
-        if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
+        if (tid == 0) { ctl->pool_n = cnt0; ctl->overflow = 0; }   // (the candidate list was emptied when the last task ended:
+                                                                   //  waves push to it while they count, behind no barrier)
         if (tid == keep - 1 || (tid == 0 && cnt0 < keep)) ctl->thr = cnt0 >= keep ? my_key : kKeyInf;
         // (no barrier: nothing of the state is read before the first pass's count barrier -- the bound and the pool's
         // size come from what the filter noted of the needle, the threshold is read behind that barrier)
@@ -2074,7 +2112,51 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
           PATH_FLAG(A, q, (L ? kPathWsLeftOut : 0u) | (wide ? kPathWsWide : 0u) | (n_units > 64 ? kPathWsTableWalk : 0u));
           WS_CLOCK(6);                                       // the left-out set chosen, the units published
 
-          for (uint32_t h = 0; h < (wide ? 2u : 1u); ++h) {
+          // The usual pass -- a threshold, four bits enough, the units listed -- finds its candidates WHILE counting
+          // (ws_bump8_cross) and then only clears the window's counters, blindly; the others count first and scan.
+          const bool cross = !robust && !wide && n_units <= 64;
+          if (cross) {
+            for (uint32_t k0 = wid; k0 < n_units; k0 += kWsAhead * kWsNW) {
+              uint4 u[kWsAhead];
+#pragma unroll
+              for (uint32_t i = 0; i < kWsAhead; ++i) {
+                const uint32_t k = k0 + i * kWsNW;
+                const uint2 d = s_units[j][min(k, 63u)];
+                const uint32_t c = __builtin_amdgcn_readfirstlane(d.x);
+                const uint32_t e = k < n_units ? __builtin_amdgcn_readfirstlane(d.y) : 0u;
+                u[i] = load_group(A.ent, c + lane * 8, e);
+                if (STATS(A) && k < n_units) { st_ent += min(512u, e - c); ++st_units; }
+              }
+#pragma unroll
+              for (uint32_t i = 0; i < kWsAhead; ++i)
+                ws_bump8_cross(s_cnt, u[i], need_eff, wlen, s_cand, &s_ctl.n_cand, &s_ctl.cand_ov);
+            }
+            WS_CLOCK(7);                                     // units loaded and counted
+            ws_barrier();
+            WS_CLOCK(2);                                     // barrier after the count
+            if (was_first) thr = ctl->thr;                   // (the task's state is visible from here on)
+            // every candidate's count as it stands now that all postings are in (it may have grown past need_eff)
+            if (!s_ctl.cand_ov) {
+              const uint32_t n_cand = s_ctl.n_cand;
+#pragma unroll
+              for (uint32_t c = 0; c < 2; ++c) {
+                const uint32_t at = tid + c * kWsNT;
+                if (at < n_cand) {
+                  const uint32_t r = s_cand[at];
+                  const uint32_t word = s_cnt[(r >> 2) & 0x1FFFu];
+                  s_cand[at] = r | (((word >> ((((r & 3u) | ((r >> 15) << 2))) * 4u)) & 15u) << 16);
+                }
+              }
+            }
+            ws_barrier();                                    // counts read before anybody clears
+            for (uint32_t i = tid; i < kWsCntWords / 4; i += kWsNT) {
+              uint32_t z = 0;
+              asm volatile("" : "+v"(z));
+              cnt128[i] = make_uint4(z, z, z, z);
+            }
+            WS_CLOCK(3);
+          }
+          for (uint32_t h = 0; !cross && h < (wide ? 2u : 1u); ++h) {
             // ---- count: unit k belongs to wave k mod 4; four loads travel together ---------------------
             if (n_units <= 64) {
               for (uint32_t k0 = wid; k0 < n_units; k0 += kWsAhead * kWsNW) {
@@ -2215,6 +2297,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
           }
           if (tid == 0) A.counts[q] = pn;
         }
+        if (tid == 0) { s_ctl.n_cand = 0; s_ctl.cand_ov = 0; }
         ws_barrier();                                        // pool and control quiet before the next task
         WS_CLOCK(5);
       }
