@@ -2135,25 +2135,6 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
             ws_barrier();
             WS_CLOCK(2);                                     // barrier after the count
             if (was_first) thr = ctl->thr;                   // (the task's state is visible from here on)
-            // every candidate's count as it stands now that all postings are in (it may have grown past need_eff)
-            if (!s_ctl.cand_ov) {
-              const uint32_t n_cand = s_ctl.n_cand;
-#pragma unroll
-              for (uint32_t c = 0; c < 2; ++c) {
-                const uint32_t at = tid + c * kWsNT;
-                if (at < n_cand) {
-                  const uint32_t r = s_cand[at];
-                  const uint32_t word = s_cnt[(r >> 2) & 0x1FFFu];
-                  s_cand[at] = r | (((word >> ((((r & 3u) | ((r >> 15) << 2))) * 4u)) & 15u) << 16);
-                }
-              }
-            }
-            ws_barrier();                                    // counts read before anybody clears
-            for (uint32_t i = tid; i < kWsCntWords / 4; i += kWsNT) {
-              uint32_t z = 0;
-              asm volatile("" : "+v"(z));
-              cnt128[i] = make_uint4(z, z, z, z);
-            }
             WS_CLOCK(3);
           }
           for (uint32_t h = 0; !cross && h < (wide ? 2u : 1u); ++h) {
@@ -2238,6 +2219,12 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
             const uint32_t c0 = has0 ? s_cand[tid] : 0u, c1 = has1 ? s_cand[tid + kWsNT] : 0u;
             const uint32_t r0 = c0 & 0xFFFFu, r1 = c1 & 0xFFFFu;
             uint32_t t0 = c0 >> 16, t1 = c1 >> 16;
+            if (cross) {
+              // the list holds ranks only: a candidate's count as it stands now that all postings are in (it may
+              // have grown past need_eff since the candidate was noted)
+              t0 = (s_cnt[(r0 >> 2) & 0x1FFFu] >> (((r0 & 3u) | ((r0 >> 15) << 2)) * 4u)) & 15u;
+              t1 = (s_cnt[(r1 >> 2) & 0x1FFFu] >> (((r1 & 3u) | ((r1 >> 15) << 2)) * 4u)) & 15u;
+            }
             if (__ballot(has0)) {
               for (uint32_t i0 = 0; i0 < L; i0 += 4) {
                 uint32_t x0[4], x1[4];
@@ -2258,6 +2245,15 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
               if (has1) ws_admit(A, ctl, s_pool, thr, T, wbase, r1, t1);
             }
             ws_barrier();
+          }
+          if (cross) {
+            // the counters, cleared blindly (everybody's reads of them lie behind the barrier above; an overflowed
+            // list is not read at all) -- complete before the barriers every way to the next count leads through
+            for (uint32_t i = tid; i < kWsCntWords / 4; i += kWsNT) {
+              uint32_t z = 0;
+              asm volatile("" : "+v"(z));
+              cnt128[i] = make_uint4(z, z, z, z);
+            }
           }
           WS_CLOCK(4);
           // ---- select ---------------------------------------------------------------------------
