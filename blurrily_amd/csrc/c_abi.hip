@@ -97,6 +97,11 @@ struct trigram_map_t {
   IndexBuildOptions build_opt;          // ws_enabled, ws_min_windows, ws_min_slice, dense_min
   uint32_t    ws_cmin = 3;              // a left-out slice must leave at least this many counted matches
   uint32_t    ws_min_needles = 16384;   // smaller batches: needle-major
+  bool        ws_autotune = true;       // measure the choice per class of batch on first use (run_find_on)
+  uint32_t    ws_static_slice = 2200;   // the static rule's mean_hit_slice (autotune off): break-even of the skewed family
+  int         ws_choice[6] = {0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major
+  float       ws_tuned_ms[6][2] = {};   // what the measurement saw (needle-major, window-major)
+  hipEvent_t  tune_ev[3] = {nullptr, nullptr, nullptr};
   int         n_cus = 0;
   bool        timing = false;
   bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
@@ -149,6 +154,7 @@ int ensure_device(trigram_map m) {
   if (!have_base || lacks_bitmaps || m->log_overflow || m->pending.size() + m->n_tomb > log_budget(m)) {
     if (device_index_build(*m->host, &m->dev, m->build_opt) < 0) return -1;
     ++m->base_builds;
+    std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);     // a new image: measure again
     clear_log(m);
     if (m->n_cus == 0) {
       hipDeviceProp_t prop;
@@ -345,17 +351,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // Large batches over many windows: the window-major sweep (find_kernels.hip, wsweep_kernel).
     // Phase 1 -- the needle-major kernel over the window pair of every needle's own length class --
     // seeds the needles' states; one launch per window follows; keys become rows at the end.
-    // Which images it runs on at all -- enough windows, slices big enough -- is IndexBuildOptions::wants_bitmaps
-    // (an image it cannot run on carries no bitmaps).  How big the slices must be depends on the batch and the
-    // limit: measured (tools/gate_probe.py, table in DESIGN.md section 5: both sweeps on haystacks from plain to
-    // hot-trigram, 16 k .. 1 M needles, limits 10 and 100) the two sweeps break even at mean_hit_slice ~1700 for
-    // batches of 65 536 needles or more at limit 10, ~3500 for smaller batches or for limit 100, and a small
-    // batch at limit 100 loses even at 8500; the gate sits above the break-even (1.1x or better where taken).
-    const double slice_factor = (n < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
-    const bool use_ws = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.d_bm_id != nullptr &&
-                        m->build_opt.wants_bitmaps(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull &&
-                        ix.mean_hit_slice >= slice_factor * double(m->build_opt.ws_min_slice);
-    if (use_ws) {
+    auto run_ws = [&]() -> int {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
       a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = m->ws_cmin;
@@ -380,23 +376,68 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
         if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
-    }
-    // needles with <= 127 distinct trigrams: byte counters, up to 1024 rows per pass
-    for (uint32_t base = 0; !use_ws && ranges <= 1 && base < limit; base += 1024) {
-      a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
-      a.pass_base = base; a.keep = std::min<uint32_t>(1024, limit - base);
-      a.pool_cap = find_pool_cap(a.keep);
-      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-      const uint32_t grid = uint32_t(std::min<size_t>(n, wgs));
-      a.short_only = 1;                              // needles with <= 64 distinct trigrams
-      if (do_launch_find(cb, a, false, grid, stream) < 0) return -1;
-      a.short_only = 0;
-      if (maybe_mid) {                               // 65..127: the tokeniser's mid list
-        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+      a.bm_id = nullptr; a.bitmaps = nullptr;
+      return 0;
+    };
+    // needles with <= 127 distinct trigrams, needle-major: byte counters, up to 1024 rows per pass
+    auto run_nm = [&]() -> int {
+      for (uint32_t base = 0; base < limit; base += 1024) {
+        a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
+        a.pass_base = base; a.keep = std::min<uint32_t>(1024, limit - base);
+        a.pool_cap = find_pool_cap(a.keep);
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
-        if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+        const uint32_t grid = uint32_t(std::min<size_t>(n, wgs));
+        a.short_only = 1;                              // needles with <= 64 distinct trigrams
+        if (do_launch_find(cb, a, false, grid, stream) < 0) return -1;
+        a.short_only = 0;
+        if (maybe_mid) {                               // 65..127: the tokeniser's mid list
+          a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+          if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+          if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+        }
+      }
+      return 0;
+    };
+    // WHICH sweep: an image can take the window-major one at all if it has bitmaps (IndexBuildOptions::
+    // wants_bitmaps: enough windows, mean_hit_slice at or above "ws_min_slice" -- below it the sweep lost on every
+    // haystack measured).  Above it no statistic of the image predicts the winner across kinds of haystack
+    // (tools/gate_probe.py, DESIGN.md section 5: at the same mean_hit_slice one family wins 1.4x where another
+    // loses 0.7x), so the choice is MEASURED: the first batch of a class -- limit up to / above 32, by batch size
+    // 16 384.. / 65 536.. / 262 144.. -- on an image runs both sweeps (they give the same rows; the call waits for
+    // them, once), and the faster one serves that class until the image is rebuilt or an option changes.  With
+    // "ws_autotune" 0 (or while request counters are collected) the static rule of the measured table applies.
+    bool use_ws = false;
+    const bool ws_possible = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.d_bm_id != nullptr &&
+                             m->build_opt.wants_bitmaps(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
+    if (ws_possible) {
+      const double slice_factor = (n < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
+      const bool static_rule = ix.mean_hit_slice >= slice_factor * double(m->ws_static_slice);
+      const int cls = (limit > 32 ? 3 : 0) + (n < 65536 ? 0 : n < 262144 ? 1 : 2);
+      if (!m->ws_autotune || cb || &ix != &m->dev) {
+        use_ws = static_rule;
+      } else if (m->ws_choice[cls] == 0) {             // measure this class, once
+        if (!m->tune_ev[0])
+          for (auto& e : m->tune_ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
+        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[0], stream));
+        if (run_nm() < 0) return -1;
+        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[1], stream));
+        if (run_ws() < 0) return -1;
+        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[2], stream));
+        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[2]));
+        float nm_ms = 0.f, ws_ms = 0.f;
+        BLURRILY_HIP_TRY(hipEventElapsedTime(&nm_ms, m->tune_ev[0], m->tune_ev[1]));
+        BLURRILY_HIP_TRY(hipEventElapsedTime(&ws_ms, m->tune_ev[1], m->tune_ev[2]));
+        m->ws_choice[cls] = ws_ms < nm_ms ? 2 : 1;
+        m->ws_tuned_ms[cls][0] = nm_ms; m->ws_tuned_ms[cls][1] = ws_ms;
+        goto short_needles_done;                       // (both ran: the rows are there)
+      } else {
+        use_ws = m->ws_choice[cls] == 2;
       }
     }
+    if (ranges <= 1) {
+      if ((use_ws ? run_ws() : run_nm()) < 0) return -1;
+    }
+  short_needles_done:
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
     if (maybe_long) {
       for (uint32_t base = 0; base < limit; base += 256) {
@@ -494,6 +535,7 @@ int blurrily_storage_close(trigram_map* haystack) {
     if (m->d_phase) (void)hipFree(m->d_phase);
     m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->tune_ev) if (e) (void)hipEventDestroy(e);
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
     m->ws_io_out.release(); m->ws_tomb.release(); m->ws_flags.release();
     if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -839,7 +881,8 @@ namespace {
 struct OptionSlot { const char* key; long long lo, hi; };
 constexpr OptionSlot kMapOptions[] = {
     {"wsweep", 0, 1}, {"ws_cmin", 1, 64}, {"ws_min_windows", 0, 1 << 20}, {"ws_min_needles", 0, 1ll << 32},
-    {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}, {"host_chunk", 0, 1ll << 30}};
+    {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}, {"host_chunk", 0, 1ll << 30},
+    {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -869,7 +912,11 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
       m->build_opt.dense_min = uint32_t(value);
       break;
     case 6: m->host_chunk = uint32_t(value); break;
+    case 7: m->ws_autotune = value != 0; break;
+    case 8: m->ws_static_slice = uint32_t(value); break;
+    case 9: break;                                       // (value 0 only: forget what was measured)
   }
+  if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
 }
 
@@ -889,6 +936,14 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 4: *value = m->build_opt.ws_min_slice; return 0;
     case 5: *value = m->build_opt.dense_min; return 0;
     case 6: *value = m->host_chunk; return 0;
+    case 7: *value = m->ws_autotune; return 0;
+    case 8: *value = m->ws_static_slice; return 0;
+    case 9: {                                            // what was measured so far: class c's choice in bits 2c+1:2c
+      long long v = 0;
+      for (int c = 0; c < 6; ++c) v |= (long long)(m->ws_choice[c]) << (2 * c);
+      *value = v;
+      return 0;
+    }
     default: errno = EINVAL; return -1;
   }
 }

@@ -100,8 +100,9 @@ struct DeviceIndex {
 struct IndexBuildOptions {
   bool     ws_enabled     = true;
   uint32_t ws_min_windows = 8;      // fewer windows: the needle-major sweep is taken whatever the batch
-  uint32_t ws_min_slice   = 2200;   // least DeviceIndex::mean_hit_slice for the most favourable batches (measured
-                                    // gate; c_abi.hip raises it for small batches / large limits)
+  uint32_t ws_min_slice   = 1550;   // least DeviceIndex::mean_hit_slice of an image the sweep may be taken on at all:
+                                    // below it the sweep lost on every haystack measured; above
+                                    // it c_abi.hip MEASURES the choice per class of batch on first use
   uint32_t dense_min      = kDenseMin;
   bool wants_bitmaps(uint32_t n_windows, double mean_hit_slice) const {
     return ws_enabled && n_windows >= ws_min_windows && mean_hit_slice >= double(ws_min_slice);

@@ -197,8 +197,16 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  * Per map -- read by the map's next find; calls on one map are serial, as in the reference:
  *   "wsweep"          1 (default) / 0: whether the window-major sweep may be taken at all
  *   "ws_min_windows"  (8)     fewest windows of an image it is taken on
- *   "ws_min_slice"    (2200)  least mean postings a needle trigram finds per window (measured gate, DESIGN.md;
- *                             x1.7 for batches under 65 536 needles, x1.7 for limits above 32, x4 for both)
+ *   "ws_min_slice"    (1550)  least mean postings a needle trigram finds per window for the sweep to be possible on
+ *                             an image at all (such an image carries bitmaps of its dense slices)
+ *   "ws_autotune"     (1)     above that, which sweep serves a class of batches (limit up to / above 32; 16 384.. /
+ *                             65 536.. / 262 144.. needles) is MEASURED: the first such batch on an image runs both
+ *                             (same rows; that one call waits for them) and the faster one serves the class until the
+ *                             image is rebuilt or an option changes.  0: the static rule below
+ *   "ws_static_slice" (2200)  the static rule: window-major iff mean postings per window >= this, x1.7 for batches
+ *                             under 65 536 needles, x1.7 for limits above 32, x4 for both (measured table)
+ *   "ws_choice"       get: what has been measured (class c in bits 2c+1:2c: 0 not yet, 1 needle-major,
+ *                             2 window-major); set 0: forget it
  *   "ws_min_needles"  (16384) smallest batch it is taken for
  *   "ws_cmin"         (3)     counted matches a left-out slice must leave
  *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   /* tunables go through the ABI (nothing reads the environment): per map, and process-wide with a NULL map */
   {
     long long v = -1;
-    CHECK(blurrily_storage_get_option(map, "ws_min_slice", &v) == 0 && v == 2200);
+    CHECK(blurrily_storage_get_option(map, "ws_min_slice", &v) == 0 && v == 1550);
     CHECK(blurrily_storage_set_option(map, "wsweep", 0) == 0);
     CHECK(blurrily_storage_get_option(map, "wsweep", &v) == 0 && v == 0);
     errno = 0;

@@ -23,6 +23,8 @@ def _ws(m, **kw):
     """Lower the sweep's bounds on map `m` (blurrily_storage_set_option) so that it is reached with haystacks the
     oracle checks in seconds."""
     kw.setdefault("ws_min_slice", 0)                           # whatever the haystack's slice sizes
+    kw.setdefault("ws_static_slice", 0)
+    kw.setdefault("ws_autotune", 0)                            # ... and without measuring: the sweep it is
     for k, v in kw.items():
         m.set_option(k, v)
 
@@ -198,22 +200,47 @@ def test_both_sweeps_agree_along_the_gate(hot_pct):
     assert info["n_bitmaps"] > 0 and info["mean_hit_slice"] > 0
 
 
-def test_the_default_gate_follows_the_measured_table():
-    """Without any option set: the sweep is chosen by the image's mean_hit_slice against 2200 (x1.7 for a batch under
-    65 536 needles, x1.7 for a limit above 32, x4 for both), for batches of 16 384 needles or more over 8 windows
-    or more -- the rule DESIGN.md section 5 derives from tools/gate_probe.py's table.  An image the sweep can never
-    run on carries no bitmaps."""
+def test_the_sweep_is_chosen_by_measurement_and_the_static_rule_holds_without_it():
+    """Default options.  An image whose mean_hit_slice is below "ws_min_slice" carries no bitmaps and never takes
+    the window-major sweep.  On one that does, the first batch of a class (limit up to / above 32; by batch size)
+    runs both sweeps and notes the faster ("ws_choice"); the rows are the oracle's whichever way.  With
+    "ws_autotune" 0 the static rule of DESIGN.md section 5 applies: mean_hit_slice against "ws_static_slice" (x1.7
+    for a batch under 65 536 needles, x1.7 for a limit above 32, x4 for both)."""
     for gen, kw in ((W.skewed, dict(n=600000, seed=45)), (W.geonames, dict(n=600000, vocab=80000, seed=41))):
         hay, off = gen(**kw)
-        m = RawMap()
-        m.put_many_packed(hay, off, np.arange(1, len(off), dtype=np.uint32))
+        m, o = _pair(hay, off)
         m.sync_device()
         info = m.device_info()
         mhs = info["mean_hit_slice"]
-        assert (info["n_bitmaps"] > 0) == (mhs >= 2200 and info["n_windows"] >= 8), info
+        eligible = mhs >= 1550 and info["n_windows"] >= 8
+        assert (info["n_bitmaps"] > 0) == eligible, info
+        # ---- measured choice ---------------------------------------------------------------------------
+        assert m.get_option("ws_choice") == 0
+        for n_q, limit, cls in ((70000, 10, 1), (20000, 10, 0), (20000, 100, 3), (8000, 10, None)):
+            q, qo = W.queries(hay, off, n_q, 90)
+            rows, counts = m.find_batch_packed(q, qo, limit)                  # (the class's first batch: both sweeps)
+            choice = m.get_option("ws_choice")
+            if cls is not None:
+                assert ((choice >> (2 * cls)) & 3 != 0) == eligible, (gen.__name__, n_q, limit, choice)
+            rows2, counts2 = m.find_batch_packed(q, qo, limit)                # (the chosen one)
+            assert m.get_option("ws_choice") == choice
+            live = np.arange(limit)[None, :] < counts[:, None].astype(np.int64)
+            assert np.array_equal(counts, counts2)
+            assert np.array_equal(np.where(live[:, :, None], rows, 0), np.where(live[:, :, None], rows2, 0))
+            idx = np.arange(0, n_q, 50, dtype=np.uint32)
+            want = o.batch(q, qo, idx=idx, limit=limit)
+            assert np.array_equal(counts[idx], want["counts"])
+            live_s = np.arange(limit)[None, :] < want["counts"][:, None].astype(np.int64)
+            assert np.array_equal(np.where(live_s[:, :, None], rows[idx], 0), np.where(live_s[:, :, None], want["rows"], 0))
+        if not eligible:
+            assert m.get_option("ws_choice") == 0
+        m.set_option("ws_choice", 0)
+        assert m.get_option("ws_choice") == 0
+        # ---- the static rule ---------------------------------------------------------------------------
+        m.set_option("ws_autotune", 0)
         for n_q, limit in ((70000, 10), (20000, 10), (70000, 100), (20000, 100), (8000, 10)):
             factor = (4.0 if limit > 32 else 1.7) if n_q < 65536 else (1.7 if limit > 32 else 1.0)
-            expect_ws = n_q >= 16384 and info["n_windows"] >= 8 and mhs >= factor * 2200
+            expect_ws = eligible and n_q >= 16384 and mhs >= factor * 2200
             q, qo = W.queries(hay, off, n_q, 90)
             m.set_stats(True)
             m.find_batch_packed(q, qo, limit)

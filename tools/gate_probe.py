@@ -36,6 +36,8 @@ def main():
         hay, off = gen()
         m = RawMap()
         m.set_option("ws_min_slice", 0)                 # bitmaps built whatever the slice sizes: both sweeps can run
+        m.set_option("ws_static_slice", 0)
+        m.set_option("ws_autotune", 0)                  # the sweep asked for ("wsweep" 0 / 1), not the measured choice
         m.put_many_packed(hay, off, np.arange(1, len(off), dtype=np.uint32))
         m.sync_device()
         info = m.device_info()

@@ -12,7 +12,7 @@ for name, nq in (("skewed", 100000), ("geonames", 300000)):
     limit = W.BENCH_WORKLOADS[name]["limit"]
     hay, off = W.bench_haystack(name)
     m = RawMap()
-    m.set_option("ws_min_slice", 0)
+    m.set_option("ws_min_slice", 0); m.set_option("ws_static_slice", 0); m.set_option("ws_autotune", 0)
     m.put_many_packed(hay, off, np.arange(1, len(off), dtype=np.uint32))
     m.sync_device()
     q, qo = W.queries(hay, off, nq, 3000)

@@ -16,6 +16,7 @@ n = len(off) - 1
 m = RawMap()
 m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
 m.set_option("ws_min_slice", 0)          # (before the image is built: it then carries the bitmaps)
+m.set_option("ws_static_slice", 0); m.set_option("ws_autotune", 0)      # the sweep asked for, not the measured choice
 m.sync_device()
 print("windows", m.device_info()["n_windows"], "bytes", m.device_info()["device_bytes"], flush=True)
 q, qo = W.queries(hay, off, nq, 3000)

@@ -16,6 +16,7 @@ n = len(off) - 1
 m = RawMap()
 m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
 m.set_option("ws_min_slice", int(os.environ.get("WS_MIN_SLICE", "0")))
+m.set_option("ws_static_slice", 0); m.set_option("ws_autotune", 0)
 m.set_option("wsweep", int(os.environ.get("WSWEEP", "1")))     # WSWEEP=0: the needle-major sweep
 m.sync_device()
 q, qo = W.queries(hay, off, nq, 3000)

@@ -14,7 +14,7 @@ n = len(off) - 1
 q, qo = W.queries(hay, off, nq, 3000)
 for dense in (512, 1024, 2048, 4096):
     m = RawMap()
-    m.set_option("ws_min_slice", 0)
+    m.set_option("ws_min_slice", 0); m.set_option("ws_static_slice", 0); m.set_option("ws_autotune", 0)
     m.set_option("dense_min", dense)
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     m.sync_device()
