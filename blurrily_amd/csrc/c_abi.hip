@@ -627,7 +627,7 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
 // needles travel to the device (s_in) and chunk k-1's rows travel back (s_out) -- both through pinned staging,
 // which the host fills / drains meanwhile.  Two slots by turns; a slot is reused only after its rows have been
 // copied out to the caller.  Each element is still exactly one blurrily_storage_find.
-static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
+static int find_batch_chunked_run(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                               trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii, size_t chunk) {
   auto& P = m->pipe;
   if (!P.s_in) {
@@ -723,6 +723,17 @@ static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t*
   }
   if (drain(int(k & 1)) < 0 || drain(int((k + 1) & 1)) < 0) return -1;
   return 0;
+}
+
+static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
+                              trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii, size_t chunk) {
+  const int rc = find_batch_chunked_run(m, packed, offsets, n, limit, results, counts, raw, non_ascii, chunk);
+  if (rc < 0) {                                       // chunks may still be in flight on the three streams: let them
+    const int e = errno;                              // finish before anybody reuses the slots
+    (void)hipDeviceSynchronize();
+    errno = e;
+  }
+  return rc;
 }
 
 // Host-buffer batch: needles in, rows out.  raw = the needles are un-normalised ASCII (see
