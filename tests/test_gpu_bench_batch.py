@@ -226,5 +226,5 @@ def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
     # candidates a full pool drops depends on the order its atomics land in)
     assert abs(plain["roofline"]["traffic"] - launched["roofline"]["traffic"]) / plain["roofline"]["traffic"] < 1e-3
     assert plain["roofline"]["counters"]["tasks"] == launched["roofline"]["counters"]["tasks"]
-    assert abs(plain["value"] - launched["value"]) / plain["value"] < 0.15, (plain["value"], launched["value"])
+    assert abs(plain["value"] - launched["value"]) / plain["value"] < 0.25, (plain["value"], launched["value"])
     assert "unpinned" in plain and plain["roofline"]["hbm_only_frac"] is None
