@@ -104,16 +104,13 @@ def test_the_benched_call_on_the_benched_batch(name, n_sample, per_class):
                                                                   want["rows"][k, :c].tolist())
 
     # ---- the first 100 000 needles, row for row, through digests of the oracle's result blocks ------
-    import os
-    from helpers import GOLDEN
     covered = min(n_q, 100_000)
-    if os.path.exists(os.path.join(GOLDEN, f"digest_{name}.json")) or not os.environ.get("BLURRILY_DIGESTS_PENDING"):
-        gold = load_golden(f"digest_{name}.json")
-        assert gold["limit"] == limit and gold["needles"] == covered
-        got = block_digests(rows[:covered], counts[:covered], gold["block"])
-        bad = [k for k, (a, b) in enumerate(zip(got, gold["digests"])) if a != b]
-        assert not bad and len(got) == len(gold["digests"]), f"result blocks {bad[:8]} (of {gold['block']} needles) differ"
-        assert int(counts[:covered].sum()) == gold["sum_counts"]
+    gold = load_golden(f"digest_{name}.json")
+    assert gold["limit"] == limit and gold["needles"] == covered
+    got = block_digests(rows[:covered], counts[:covered], gold["block"])
+    bad = [k for k, (a, b) in enumerate(zip(got, gold["digests"])) if a != b]
+    assert not bad and len(got) == len(gold["digests"]), f"result blocks {bad[:8]} (of {gold['block']} needles) differ"
+    assert int(counts[:covered].sum()) == gold["sum_counts"]
 
     # ---- by kernel path: the counted build says which paths every needle took ----------------------
     m.set_stats(True)
