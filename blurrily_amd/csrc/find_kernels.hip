@@ -990,7 +990,11 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // The next visited window is decided one step ahead (windows that cannot hold a candidate are
 // stepped over without a barrier), so the producing wave has the table in registers before it
 // needs it.
-constexpr uint32_t kRingUnits = 256;                            // descriptors per ring slot
+// Descriptors per ring slot: the dynamic LDS behind the counters is one budget (two workgroups per CU), shared by
+// the candidate pool and the ring -- a small pool (limit <= 128) leaves room for 512 units a step, a large one for
+// 256.  A step with more units than that is walked by every wave from the table itself (BLURRILY_COUNT_WALK).
+constexpr uint32_t kRingUnitsMax = 512;
+__host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) { return pool_cap <= 512 ? kRingUnitsMax : 256u; }
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two
 // row broadcasts of gfx9): ten VALU instructions, against six dependent ds_bpermute round trips for __shfl_up.
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
@@ -1006,15 +1010,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
 }
 
 struct UnitRing {
-  uint2    desc[2][kRingUnits];                                 // .x first entry of the unit, .y end of its slice
   // what a step starts with, ONE 8-byte read: .x the step the slot's units belong to (past the end: none left),
   // .y the number of units (kRingWalk: too many, walk the table) | the scan's admission bound << 16 (0: the slow
   // scan, which works it out itself -- cold start)
   uint2    hdr[2];
   uint32_t visit[2];                                            // the visit index chosen most recently, by turns
+  uint32_t pad_[2];
+  // behind it: desc[2][ring_units_for(pool_cap)], .x first entry of the unit, .y end of its slice
 };
+__device__ __forceinline__ uint2* ring_slot(UnitRing* ring, uint32_t slot, uint32_t ring_units) {
+  return reinterpret_cast<uint2*>(ring + 1) + (slot ? ring_units : 0u);
+}
 constexpr uint32_t kRingWalk = 0xFFFFu;
-static_assert(kRingUnits < kRingWalk, "a unit count is sixteen bits of the step header");
+static_assert(kRingUnitsMax < kRingWalk, "a unit count is sixteen bits of the step header");
 
 // why sweep_coop's hot loop was left
 enum : uint32_t { kLeftDone = 0, kLeftWalk = 1, kLeftSlowScan = 2, kLeftSelect = 3 };
@@ -1036,6 +1044,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
   const uint32_t n_visit = v1 - v0;
   uint4* const cnt128 = reinterpret_cast<uint4*>(cnt32);
+  const uint32_t ring_units = ring_units_for(A.pool_cap);
 #define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
   // most trigrams of the needle a reference of the step's window(s) can hold
 #define BLURRILY_WMT_AT(i_, out_)                                                \
@@ -1095,14 +1104,15 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
     const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
-    if (total_ > kRingUnits) {                                                   \
+    if (total_ > ring_units) {                                                   \
       BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk);                                \
     } else {                                                                     \
+      uint2* const slot_ = ring_slot(ring, s_, ring_units);                      \
       uint32_t at_ = incl_ - units0_ - units1_;                                  \
       for (uint32_t j_ = 0; j_ < units0_; ++j_, ++at_)                           \
-        ring->desc[s_][at_] = make_uint2(A0 + j_ * 512, B0);                     \
+        slot_[at_] = make_uint2(A0 + j_ * 512, B0);                              \
       for (uint32_t j_ = 0; j_ < units1_; ++j_, ++at_)                           \
-        ring->desc[s_][at_] = make_uint2((A1 + j_ * 512) | 1u, B1);              \
+        slot_[at_] = make_uint2((A1 + j_ * 512) | 1u, B1);                       \
       BLURRILY_PUBLISH_HDR(s_, step_, total_);                                   \
     }                                                                            \
   } while (0)
@@ -1111,15 +1121,17 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // predicate -- an SGPR pair -- beside the unit in flight: no sentinels to fill idle lanes with, no liveness
   // test before the atomics.  A unit's address is a scalar base (its first entry) plus the lane's 16 bytes:
   // nothing per unit and lane but the load itself and one compare.  (Up to four of a wave's units loaded before
-  // the first is counted -- four loads in flight -- measured in round 3: 3.2 % SLOWER, 317.2 vs 307.4 ms.)
+  // the first is counted -- four loads in flight -- measured in round 3: 3.2 % SLOWER, 317.2 vs 307.4 ms.  Starting
+  // the deal behind the two waves with a turn, so that they are the last to get one unit more: 0.7 % slower.)
 #define BLURRILY_COUNT_UNITS(s_, n_, have_first_)                                \
   do {                                                                           \
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
     uint32_t pend_h_ = 0;                                                        \
     bool pend_live_ = false;                                                     \
+    const uint2* const slot_ = ring_slot(ring, s_, ring_units);                  \
     for (uint32_t k_ = wid; k_ < (n_); k_ += kNW) {                              \
       uint2 d_ = d_first;                       /* (the wave's first unit: read a step ago, behind the count barrier) */ \
-      if (!(have_first_) || k_ != wid) d_ = ring->desc[s_][k_];                  \
+      if (!(have_first_) || k_ != wid) d_ = slot_[k_];                           \
       const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                  \
       const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                  \
       const uint32_t x0_ = x_ & ~7u;                                             \
@@ -1175,7 +1187,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t lane8 = lane * 8, lane16 = lane * 16;
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
-  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0;    // request counters (FindArgs::stats), wave-uniform
+  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0;    // request counters (FindArgs::stats), wave-uniform
   // Which step comes next is decided by ONE wave per step -- the one that then fetches that step's table --
   // and travels through LDS with the units (`hdr[slot]`; the visit index chosen last in `visit[]`).  The other
   // fifteen waves read one header per step instead of each running the window-bound loop, the 64-bit threshold
@@ -1196,7 +1208,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
   __syncthreads();
   uint2 h_next = ring->hdr[0];                                   // header of the step about to start ...
-  uint2 d_first = ring->desc[0][wid];                            // ... and this wave's first unit of it
+  uint2 d_first = ring_slot(ring, 0u, ring_units)[wid];  // ... and this wave's first unit of it
 
   // The sweep is a HOT LOOP of steps that need nothing special -- header, units, turns, barrier, scan with the
   // published bound, barrier, a glance at the pool -- and is left for everything else (more units than the ring
@@ -1227,7 +1239,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // they arrive under the scan instead of standing, one LDS round trip each (several hundred clocks behind the
       // other workgroup's atomics), between the scan barrier and the first load of the next step.
       h_next = ring->hdr[s ^ 1u];
-      d_first = ring->desc[s ^ 1u][wid];
+      d_first = ring_slot(ring, s ^ 1u, ring_units)[wid];
       if (n_units == 0) continue;                               // nothing of the needle in this step's windows
       const uint32_t need = hy_ >> 16;
       if (need == 0) { left = kLeftSlowScan; break; }
@@ -1248,6 +1260,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
     if (left == kLeftWalk) {
       PATH_FLAG(A, nd.q, kPathRingOverflow);
+      ++st_walk;
       BLURRILY_COUNT_WALK(p);
       BLURRILY_TAKE_TURNS(e, s);
       __syncthreads();
@@ -1269,7 +1282,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
     ++e;
     h_next = ring->hdr[e & 1];                                  // (published behind step p's count barrier)
-    d_first = ring->desc[e & 1][wid];
+    d_first = ring_slot(ring, e & 1, ring_units)[wid];
   }
   PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
@@ -1278,8 +1291,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (wid == 0) {
       atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
       atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
+      atomicAdd(&STATS(A)[kStatUnits], static_cast<unsigned long long>(st_walk));   // (needle-major: steps that walked the table)
     }
   }
+  (void)st_walk;
   __syncthreads();                                              // ring and ctl quiet before the needle ends
 #undef BLURRILY_TAKE_TURNS
 #undef BLURRILY_PRODUCER
@@ -2342,7 +2357,7 @@ __global__ void finalize_rows_kernel(const FindArgs A, const uint32_t n) {
 // dynamic LDS of find_kernel (the counters are static)
 size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
   static_assert(sizeof(Control) <= 64, "the unit ring sits 64 bytes behind the control block");
-  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 16;
+  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 2 * size_t(ring_units_for(pool_cap)) * 8 + 16;
 }
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
   return size_t(kWindowSize) * counter_bytes + find_dynamic_lds_bytes(pool_cap);
@@ -2390,7 +2405,7 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
 }
 
 uint32_t find_pool_cap(uint32_t keep) {
-  uint32_t cap = 1024;
+  uint32_t cap = keep <= 128 ? 512 : 1024;                      // (the small pool's spare LDS is the unit ring's)
   while (cap < 4 * keep && cap < 4096) cap <<= 1;
   return cap;
 }
