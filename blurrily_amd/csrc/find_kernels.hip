@@ -991,7 +991,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // stepped over without a barrier), so the producing wave has the table in registers before it
 // needs it.
 // Descriptors per ring slot: the dynamic LDS behind the counters is one budget (two workgroups per CU), shared by
-// the candidate pool and the ring -- a small pool (limit <= 128) leaves room for 512 units a step, a large one for
+// the candidate pool and the ring -- a small pool (limit <= 64) leaves room for 512 units a step, a large one for
 // 256.  A step with more units than that is walked by every wave from the table itself (BLURRILY_COUNT_WALK).
 constexpr uint32_t kRingUnitsMax = 512;
 __host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) { return pool_cap <= 512 ? kRingUnitsMax : 256u; }
@@ -1044,7 +1044,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
   const uint32_t n_visit = v1 - v0;
   uint4* const cnt128 = reinterpret_cast<uint4*>(cnt32);
-  const uint32_t ring_units = ring_units_for(A.pool_cap);
+  const uint32_t ring_units = ring_units_for(A.pool_cap), ring_rows = ring_units / kNW;   // rows: units of a wave
 #define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
   // most trigrams of the needle a reference of the step's window(s) can hold
 #define BLURRILY_WMT_AT(i_, out_)                                                \
@@ -1098,7 +1098,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | (need_ << 16));   \
   } while (0)
   // this wave publishes the units of the table into ring slot s_: a lane's even-window units,
-  // then its odd-window units
+  // then its odd-window units.  Unit k belongs to wave k mod kNW and is that wave's (k / kNW)-th: a slot is laid out
+  // wave by wave, so that ONE read -- lane j the wave's j-th unit -- hands a wave all its descriptors of a step.
+#define BLURRILY_UNIT_AT(k_) (((k_) & (kNW - 1)) * ring_rows + (k_) / kNW)
+#define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + (lane & (ring_rows - 1))])
 #define BLURRILY_PRODUCE(s_, step_, A0, B0, A1, B1)                              \
   do {                                                                           \
     const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
@@ -1110,9 +1113,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       uint2* const slot_ = ring_slot(ring, s_, ring_units);                      \
       uint32_t at_ = incl_ - units0_ - units1_;                                  \
       for (uint32_t j_ = 0; j_ < units0_; ++j_, ++at_)                           \
-        slot_[at_] = make_uint2(A0 + j_ * 512, B0);                              \
+        slot_[BLURRILY_UNIT_AT(at_)] = make_uint2(A0 + j_ * 512, B0);            \
       for (uint32_t j_ = 0; j_ < units1_; ++j_, ++at_)                           \
-        slot_[at_] = make_uint2((A1 + j_ * 512) | 1u, B1);                       \
+        slot_[BLURRILY_UNIT_AT(at_)] = make_uint2((A1 + j_ * 512) | 1u, B1);     \
       BLURRILY_PUBLISH_HDR(s_, step_, total_);                                   \
     }                                                                            \
   } while (0)
@@ -1123,17 +1126,17 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // nothing per unit and lane but the load itself and one compare.  (Up to four of a wave's units loaded before
   // the first is counted -- four loads in flight -- measured in round 3: 3.2 % SLOWER, 317.2 vs 307.4 ms.  Starting
   // the deal behind the two waves with a turn, so that they are the last to get one unit more: 0.7 % slower.)
-#define BLURRILY_COUNT_UNITS(s_, n_, have_first_)                                \
+#define BLURRILY_COUNT_UNITS(s_, n_, have_mine_)                                 \
   do {                                                                           \
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
     uint32_t pend_h_ = 0;                                                        \
     bool pend_live_ = false;                                                     \
-    const uint2* const slot_ = ring_slot(ring, s_, ring_units);                  \
-    for (uint32_t k_ = wid; k_ < (n_); k_ += kNW) {                              \
-      uint2 d_ = d_first;                       /* (the wave's first unit: read a step ago, behind the count barrier) */ \
-      if (!(have_first_) || k_ != wid) d_ = slot_[k_];                           \
-      const uint32_t x_ = __builtin_amdgcn_readfirstlane(d_.x);                  \
-      const uint32_t y_ = __builtin_amdgcn_readfirstlane(d_.y);                  \
+    uint2 dl_ = d_mine;                         /* (read a step ago, behind the count barrier) */ \
+    if (!(have_mine_)) dl_ = BLURRILY_MY_UNITS(s_);                              \
+    uint32_t j_ = 0;                                                             \
+    for (uint32_t k_ = wid; k_ < (n_); k_ += kNW, ++j_) {                        \
+      const uint32_t x_ = __builtin_amdgcn_readlane(dl_.x, j_);                  \
+      const uint32_t y_ = __builtin_amdgcn_readlane(dl_.y, j_);                  \
       const uint32_t x0_ = x_ & ~7u;                                             \
       const bool live_ = lane8 < y_ - x0_;                                       \
       uint4 v_ = pend_;                                                          \
@@ -1208,7 +1211,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
   __syncthreads();
   uint2 h_next = ring->hdr[0];                                   // header of the step about to start ...
-  uint2 d_first = ring_slot(ring, 0u, ring_units)[wid];  // ... and this wave's first unit of it
+  uint2 d_mine = BLURRILY_MY_UNITS(0u);  // ... and this wave's first unit of it
 
   // The sweep is a HOT LOOP of steps that need nothing special -- header, units, turns, barrier, scan with the
   // published bound, barrier, a glance at the pool -- and is left for everything else (more units than the ring
@@ -1235,11 +1238,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       BLURRILY_TAKE_TURNS(e, s);
       __syncthreads();                                          // counts and next descriptors visible
       PHASE_MARK(3);                                            // barrier after count
-      // The next step's header and this wave's first unit of it were published before that barrier: requested now,
+      // The next step's header and this wave's units of it were published before that barrier: requested now,
       // they arrive under the scan instead of standing, one LDS round trip each (several hundred clocks behind the
       // other workgroup's atomics), between the scan barrier and the first load of the next step.
       h_next = ring->hdr[s ^ 1u];
-      d_first = ring_slot(ring, s ^ 1u, ring_units)[wid];
+      d_mine = BLURRILY_MY_UNITS(s ^ 1u);
       if (n_units == 0) continue;                               // nothing of the needle in this step's windows
       const uint32_t need = hy_ >> 16;
       if (need == 0) { left = kLeftSlowScan; break; }
@@ -1250,6 +1253,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       PHASE_MARK(5);                                            // scan
       __syncthreads();                                          // counters are zero again
       PHASE_MARK(6);                                            // barrier after scan
+      // (Looking at the pool a count phase later -- the read requested here, used behind the next count barrier, a
+      // compaction then running with the next step counted and not yet scanned -- was built and measured in round 3:
+      // 2 % slower, 293.0 vs 287.2 ms per 500 k needles; the thresholds the headers carry are a step staler.)
       const uint2 c_ = *reinterpret_cast<const uint2*>(&ctl->pool_n);          // pool_n, overflow
       const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x), ov_ = __builtin_amdgcn_readfirstlane(c_.y);
       if (ov_ != 0 || pn_ > A.pool_cap / 2 || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
@@ -1282,7 +1288,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
     ++e;
     h_next = ring->hdr[e & 1];                                  // (published behind step p's count barrier)
-    d_first = ring_slot(ring, e & 1, ring_units)[wid];
+    d_mine = BLURRILY_MY_UNITS(e & 1);
   }
   PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
@@ -1301,6 +1307,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #undef BLURRILY_COUNT_WALK
 #undef BLURRILY_COUNT_UNITS
 #undef BLURRILY_PRODUCE
+#undef BLURRILY_MY_UNITS
+#undef BLURRILY_UNIT_AT
 #undef BLURRILY_PUBLISH_HDR
 #undef BLURRILY_FETCH_TABLE
 #undef BLURRILY_NEXT_VISIT
@@ -2405,7 +2413,9 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
 }
 
 uint32_t find_pool_cap(uint32_t keep) {
-  uint32_t cap = keep <= 128 ? 512 : 1024;                      // (the small pool's spare LDS is the unit ring's)
+  // (the small pool's spare LDS is the unit ring's; at limit 100 the ring gains nothing and 512 entries cost
+  // 1.5 % in compactions, configs[4])
+  uint32_t cap = keep <= 64 ? 512 : 1024;
   while (cap < 4 * keep && cap < 4096) cap <<= 1;
   return cap;
 }
