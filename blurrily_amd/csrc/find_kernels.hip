@@ -991,10 +991,13 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // stepped over without a barrier), so the producing wave has the table in registers before it
 // needs it.
 // Descriptors per ring slot: the dynamic LDS behind the counters is one budget (two workgroups per CU), shared by
-// the candidate pool and the ring -- a small pool (limit <= 64) leaves room for 512 units a step, a large one for
-// 256.  A step with more units than that is walked by every wave from the table itself (BLURRILY_COUNT_WALK).
+// the candidate pool and the ring -- a small pool (limit <= 64) leaves room for 512 units a step, one of 1024
+// entries for 384, a larger one for 256.  A step with more units than that is walked by every wave from the table
+// itself (BLURRILY_COUNT_WALK).
 constexpr uint32_t kRingUnitsMax = 512;
-__host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) { return pool_cap <= 512 ? kRingUnitsMax : 256u; }
+__host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) {
+  return pool_cap <= 512 ? kRingUnitsMax : pool_cap <= 1024 ? 384u : 256u;       // (multiples of the sixteen waves)
+}
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two
 // row broadcasts of gfx9): ten VALU instructions, against six dependent ds_bpermute round trips for __shfl_up.
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
@@ -1101,7 +1104,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // then its odd-window units.  Unit k belongs to wave k mod kNW and is that wave's (k / kNW)-th: a slot is laid out
   // wave by wave, so that ONE read -- lane j the wave's j-th unit -- hands a wave all its descriptors of a step.
 #define BLURRILY_UNIT_AT(k_) (((k_) & (kNW - 1)) * ring_rows + (k_) / kNW)
-#define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + (lane & (ring_rows - 1))])
+#define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + min(lane, ring_rows - 1)])
 #define BLURRILY_PRODUCE(s_, step_, A0, B0, A1, B1)                              \
   do {                                                                           \
     const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
