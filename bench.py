@@ -19,7 +19,9 @@ Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carr
                  launch -- counted exactly by the kernels themselves (blurrily_storage_set_stats,
                  the counted build of the same kernels) in an extra, untimed launch -- over the
                  HIP-event kernel time of the timed steps.  `achieved` / `frac` / `traffic` are
-                 those bytes (L2 hits included: 6 % at configs[2]), frac = rate / 8 TB/s <= 1.
+                 those bytes (L2 hits included: 6 % at configs[2]), frac = rate / 8 TB/s <= 1;
+                 `frac_of_achievable` holds the same rate against the guide's measured copy
+                 bandwidth, 6.29 TB/s.
                  `pmc` beside it is the memory-side figure of a separate rocprofv3 --pmc run
                  (profiles/traffic_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, Infinity-Cache
                  hits included), stamped with the hash of the kernel sources it was profiled at
@@ -53,6 +55,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (imported before the HIP library so both share one HIP runtime)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0    # the same guide: 6.29 TB/s measured (float4 copy, 79 % of the spec)
 # what the parity claims of this line do NOT rest on the reference for
 UNPINNED = ["reference put (storage.c:398-473 needs search_tree.c, i.e. ruby.h: haystacks reach oracle/_ref as "
             ".trigrams files written by this library)",
@@ -81,7 +84,7 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def build_haystack(name, scale):
+def build_haystack(name, scale, static_choice=False):
     import workloads as W
     from blurrily_amd import RawMap
     t0 = time.time()
@@ -89,6 +92,8 @@ def build_haystack(name, scale):
     n = len(off) - 1
     t1 = time.time()
     m = RawMap()
+    if static_choice:
+        m.set_option("ws_autotune", 0)
     entries = m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     t2 = time.time()
     m.sync_device()
@@ -202,7 +207,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
 
     spec = W.BENCH_WORKLOADS[name]
     limit = spec["limit"]
-    m, hay, hay_off, entries_resident = build_haystack(name, args.scale)
+    m, hay, hay_off, entries_resident = build_haystack(name, args.scale, getattr(args, 'static_choice', False))
     qp, qo = W.bench_needles(hay, hay_off, name, args.scale, rank, world)
     n_q = len(qo) - 1
     sum_T = W.count_trigrams(qp, qo)
@@ -398,6 +403,10 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # in-kernel (blurrily_storage_set_stats) in an extra untimed launch of THIS run; L2 hits included
                 "bound": "hbm", "achieved": req_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": req_gbs / HBM_PEAK_GBS,
+                # against what a streaming copy reaches on this chip (the guide's measured figure) -- meaningful where
+                # the requests miss the caches (configs[2]: L2 hit rate 6 %, index > Infinity Cache), an upper bound
+                # where they do not
+                "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": req_gbs / HBM_ACHIEVABLE_GBS,
                 "traffic": req_bytes,
                 "traffic_source": "in-run: bytes the kernels requested (postings, slice tables, bitmap probes, needles, "
                                   "rows), counted by the counted build of the kernels in an untimed launch of this batch",
@@ -460,6 +469,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--latency-probes", type=int, default=200)
+    ap.add_argument("--static-choice", action="store_true",
+                    help="the sweep by the static rule, not by measuring both on the first batch (PMC passes: "
+                         "every find call of the run then launches the same kernels)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -1161,7 +1161,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // (requested before the scan), the scan's registers are free -- the load of the wave's first unit of the next step
   // goes out here and travels under the barrier and the glance at the pool: 288.0 -> 281.3 ms per 500 k needles.
   // (The first TWO units loaded here and two loads kept in flight through the count: 313.0 ms, 11 % slower -- as
-  // with every other attempt at more loads in flight per wave, rounds 2 and 3.)
+  // with every other attempt at more loads in flight per wave, rounds 2 and 3.  The units' loads marked
+  // non-temporal, global_load_dwordx4 ... nt: 330.6 ms, 17 % slower -- the postings of the Geonames-scale image
+  // are 253 MB, and the 256 MiB Infinity Cache holds most of them as long as they are allowed in.)
 #define BLURRILY_PRELOAD()                                                       \
   do {                                                                           \
     const uint32_t np_ = __builtin_amdgcn_readfirstlane(h_next.x);               \

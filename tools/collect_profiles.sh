@@ -22,7 +22,7 @@ for wl in geonames words skewed; do
     name=${pass%%:*}; ctrs=${pass#*:}
     d=$out/pmc_${name}_$wl
     mkdir -p $d
-    rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --latency-probes 0 > $d/bench.json 2> $d/bench.log
+    rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $wl --steps 1 --warmup 0 --static-choice --no-cpu-baseline --latency-probes 0 > $d/bench.json 2> $d/bench.log
   done
 done
 python $root/tools/traffic_summary.py $out > $out/traffic.json

@@ -6,8 +6,9 @@ bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, per /opt/skills/guides/MI355X_MICR
 and WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports half of a wide coalesced read stream.  They
 are the L2's memory-side (fabric) request counters: Infinity-Cache hits are included, so this bounds
 HBM bytes from above; TCC_EA0_RDREQ x 64 B is reported beside it.  Summed over every kernel of the find
-path (tokeniser, find_kernel, wsweep_kernel, finalize, merges) and divided by the number of find calls
-the profiled command makes (bench.py --steps 1 --warmup 0: the timed step and the counted one).
+path (tokeniser, find_kernel, wsweep_kernel, finalize, merges) of the ONE timed step the profiled command
+makes (bench.py --steps 1 --warmup 0 --static-choice); the kernels of the counted build (namespace
+blurrily::counted: the extra, untimed launch that counts requests) are left out.
 Prints one JSON object: {workload: bytes per step, "detail": {...}}."""
 import glob
 import json
@@ -16,7 +17,7 @@ import sqlite3
 import sys
 
 OURS = ("find_kernel", "wsweep_kernel", "tokenise", "finalize_rows", "merge_", "normalise", "apply_tombstones")
-CALLS_PER_RUN = 2
+CALLS_PER_RUN = 1
 
 
 def totals(dirpath):
@@ -28,7 +29,7 @@ def totals(dirpath):
                      "from counters_collection group by kernel_name, counter_name").fetchall()
     out, per_kernel = {}, {}
     for k, n, v, disp in rows:
-        if not any(o in k for o in OURS):
+        if not any(o in k for o in OURS) or "blurrily::counted::" in k:
             continue
         out[n] = out.get(n, 0.0) + v
         short = k.replace("void ", "").replace("blurrily::(anonymous namespace)::", "").split("(")[0]
