@@ -359,7 +359,9 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       // states (a needle's best matches live there, so its threshold is tight before the other windows are
       // visited).  (Seeding through wsweep_kernel's own robust path instead -- own_pass launches -- was
       // measured: configs[2] 321 -> 355 ms per 300 k needles, configs[4] 82 -> 129 ms: without a threshold
-      // the 4-wave task floods its pool again and again where the 16-wave kernel bisects once.)
+      // the 4-wave task floods its pool again and again where the 16-wave kernel bisects once.  Phase 1 over the
+      // ONE window of the length class, in byte counters, the sibling window left to the window-major launches:
+      // configs[4] 69.0 -> 71.8 ms per 100 k needles, Geonames scale 266 -> 275 ms per 300 k, round 3.)
       if (!(a.queue = next_queue())) { errno = EIO; return -1; }
       a.short_only = 1; a.own_only = 1;
       if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
