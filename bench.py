@@ -21,7 +21,9 @@ Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carr
                  HIP-event kernel time of the timed steps.  `achieved` / `frac` / `traffic` are
                  those bytes (L2 hits included: 6 % at configs[2]), frac = rate / 8 TB/s <= 1;
                  `frac_of_achievable` holds the same rate against the guide's measured copy
-                 bandwidth, 6.29 TB/s.
+                 bandwidth, 6.29 TB/s, `frac_of_read_ceiling` against what a read-only kernel with
+                 the same access shape reaches over 327 MB on this chip, 7.49 TB/s
+                 (tools/micro/read_bw.hip).
                  `pmc` beside it is the memory-side figure of a separate rocprofv3 --pmc run
                  (profiles/traffic_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, Infinity-Cache
                  hits included), stamped with the hash of the kernel sources it was profiled at
@@ -56,6 +58,10 @@ import torch  # noqa: E402  (imported before the HIP library so both share one H
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0    # the same guide: 6.29 TB/s measured (float4 copy, 79 % of the spec)
+# what READS alone reach on this chip the way the kernel's units arrive -- pseudo-random 1 KiB per wave and load, 2 x
+# 1024 threads per CU -- over 327 MB (the resident image of configs[2]; 2 GiB, HBM only: 6.84 TB/s):
+# tools/micro/read_bw.hip, profiles/r03_read_bw.txt
+READ_CEILING_GBS = 7490.0
 # what the parity claims of this line do NOT rest on the reference for
 UNPINNED = ["reference put (storage.c:398-473 needs search_tree.c, i.e. ruby.h: haystacks reach oracle/_ref as "
             ".trigrams files written by this library)",
@@ -407,6 +413,9 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # the requests miss the caches (configs[2]: L2 hit rate 6 %, index > Infinity Cache), an upper bound
                 # where they do not
                 "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": req_gbs / HBM_ACHIEVABLE_GBS,
+                # ... and against a kernel that does nothing but read 1 KiB units of a 327 MB buffer at the same
+                # residency, measured on this chip (profiles/r03_read_bw.txt): the Infinity Cache's share included
+                "read_ceiling": READ_CEILING_GBS, "frac_of_read_ceiling": req_gbs / READ_CEILING_GBS,
                 "traffic": req_bytes,
                 "traffic_source": "in-run: bytes the kernels requested (postings, slice tables, bitmap probes, needles, "
                                   "rows), counted by the counted build of the kernels in an untimed launch of this batch",

@@ -1161,7 +1161,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // (requested before the scan), the scan's registers are free -- the load of the wave's first unit of the next step
   // goes out here and travels under the barrier and the glance at the pool: 288.0 -> 281.3 ms per 500 k needles.
   // (The first TWO units loaded here and two loads kept in flight through the count: 313.0 ms, 11 % slower -- as
-  // with every other attempt at more loads in flight per wave, rounds 2 and 3.  The units' loads marked
+  // with every other attempt at more loads in flight per wave, rounds 2 and 3.  Two units loaded here and ONE load
+  // in flight through the count: 330 ms while the compiler kept the second unit in scratch -- a value carried through
+  // the rare paths is spilled where it is loaded --, 289.4 vs 281.9 ms, 2.7 % slower, once it was declared dead there.
+  // A read-only kernel with this shape of access reaches 7.5 TB/s on the chip with one load in flight per wave
+  // (tools/micro/read_bw.hip): what the loads wait for is not more of them.  The units' loads marked
   // non-temporal, global_load_dwordx4 ... nt: 330.6 ms, 17 % slower -- the postings of the Geonames-scale image
   // are 253 MB, and the 256 MiB Infinity Cache holds most of them as long as they are allowed in.)
 #define BLURRILY_PRELOAD()                                                       \
