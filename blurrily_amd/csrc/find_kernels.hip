@@ -72,7 +72,8 @@ constexpr uint32_t kCodeChunk = 128;   // needle trigrams staged per count pass
 
 constexpr int      kFindThreads    = 1024; // find_kernel's workgroup: sixteen waves, two workgroups per CU (256 and 512 were
                                            // measured slower in round 1 and are no longer built)
-constexpr uint32_t kRankSortMax    = 256;  // pools up to this size are compacted by rank counting, larger ones by a bitonic sort
+constexpr uint32_t kRankSortMax    = 512;   // pools up to this size are compacted by rank counting (two keys per read), larger ones by
+                                            // a bitonic sort (256 -> 512: -0.7 % at configs[2]; 1 024: +1 % at configs[4], limit 100)
 constexpr int      kSerialPrio     = 2;    // wave priority in a workgroup's serial sections (between needles, compaction, cold start)
 
 // Phase profile (counted build only): wave 0's shader-clock time per phase of the sweep,
@@ -534,8 +535,14 @@ __device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t ca
     // barriers instead of the bitonic network's dozens.
     const unsigned long long mine = tid < n ? pool[tid] : kKeyInf;
     uint32_t below = 0;
-    if (tid < n)
-      for (uint32_t j = 0; j < n; ++j) below += pool[j] < mine;     // same address in every lane: a broadcast
+    if (tid < n) {                                                   // (same address in every lane: a broadcast)
+      const uint32_t n2 = n & ~1u;
+      for (uint32_t j = 0; j < n2; j += 2) {                         // two keys per read
+        const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(pool + j);
+        below += uint32_t(two.x < mine) + uint32_t(two.y < mine);
+      }
+      if (n2 < n) below += pool[n2] < mine;
+    }
     __syncthreads();
     if (tid < n && below < keep) pool[below] = mine;
     __syncthreads();
