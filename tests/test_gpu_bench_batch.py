@@ -225,3 +225,8 @@ def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
     assert plain["roofline"]["counters"]["tasks"] == launched["roofline"]["counters"]["tasks"]
     assert abs(plain["value"] - launched["value"]) / plain["value"] < 0.25, (plain["value"], launched["value"])
     assert "unpinned" in plain and plain["roofline"]["hbm_only_frac"] is None
+    # the three yardsticks of the one rate: the spec, the guide's copy figure, the measured read ceiling
+    r = plain["roofline"]
+    assert r["peak"] == 8000.0 and r["achievable_peak"] == 6290.0 and r["read_ceiling"] == 7490.0
+    assert abs(r["frac"] * r["peak"] - r["achieved"]) < 1e-6 * r["achieved"]
+    assert abs(r["frac_of_read_ceiling"] * r["read_ceiling"] - r["achieved"]) < 1e-6 * r["achieved"]
