@@ -13,10 +13,6 @@
 #include <thread>
 #include <vector>
 
-#ifndef BLURRILY_DEAL_GREEDY
-#define BLURRILY_DEAL_GREEDY 0         // 1: a unit dealt half after half, one posting per bank (see step 3: measured, no gain)
-#endif
-
 namespace blurrily {
 
 namespace {
@@ -365,42 +361,11 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
         uint32_t cap[16];
         for (uint32_t h = 0; h < 16; ++h) cap[h] = (h & 1) ? (G > 32 ? G - 32 : 0) : std::min(G, 32u);
         std::fill(sl + u0, sl + u0 + len, kPadRank);
-#if BLURRILY_DEAL_GREEDY
-        // Half after half: one posting from every bank that still has any -- the banks with the most left
-        // first when the half has fewer lanes than there are such banks -- and only when no bank is untouched
-        // a second (third ...) one from the fullest banks: the doubles an uneven bank histogram makes
-        // unavoidable gather in the last few halves (CPU model: 25.8 LDS cycles per full unit against 31.9 for
-        // the round robin below, 16 being the floor).  Measured on the configs[2] haystack, 300 k needles:
-        // SQ_LDS_BANK_CONFLICT -37 %, SQ_LDS_IDX_ACTIVE -10 % -- and the kernel 1 % SLOWER (351.3 vs 347.7 ms
-        // per 500 k needles, same box): the count phase does not wait for the LDS pipe's cycles.  Left off.
-        uint32_t b_at[33], rem[32], idx[32];
-        {
-          uint32_t i = 0;
-          for (uint32_t b = 0; b < 32; ++b) {
-            b_at[b] = i;
-            while (i < real && ((tmp[i] >> 2) & 31u) == b) ++i;
-            rem[b] = i - b_at[b];
-          }
-          b_at[32] = i;
-        }
-        for (uint32_t h = 0; h < 16; ++h) {
-          uint32_t filled = 0;
-          while (filled < cap[h]) {
-            for (uint32_t b = 0; b < 32; ++b) idx[b] = b;
-            std::sort(idx, idx + 32, [&](uint32_t x, uint32_t y) { return rem[x] != rem[y] ? rem[x] > rem[y] : x < y; });
-            bool took = false;
-            for (uint32_t k = 0; k < 32 && filled < cap[h]; ++k) {
-              const uint32_t b = idx[k];
-              if (!rem[b]) break;
-              const uint32_t lane = (h & 1) * 32 + filled++;
-              sl[u0 + lane * 8 + (h >> 1)] = tmp[b_at[b]++];
-              --rem[b];
-              took = true;
-            }
-            if (!took) break;
-          }
-        }
-#else
+        // (Dealt greedily instead -- half after half one posting from every bank that still has any, the fullest
+        // banks first, doubles only when no bank is untouched; CPU model: 25.8 LDS cycles per full unit against 31.9
+        // for the round robin below, 16 being the floor -- measured in round 2 on the configs[2] haystack, 300 k
+        // needles: SQ_LDS_BANK_CONFLICT -37 %, SQ_LDS_IDX_ACTIVE -10 %, and the kernel 1 % SLOWER, 351.3 vs 347.7 ms
+        // per 500 k needles, same box.  The code went with round 3.)
         uint32_t cnt[16];
         for (uint32_t h = 0; h < 16; ++h) cnt[h] = 0;
         uint32_t h = 0;
@@ -410,7 +375,6 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
           sl[u0 + lane * 8 + (h >> 1)] = tmp[i];
           h = (h + 1) & 15;
         }
-#endif
         // a live lane keeps a real rank in its first slot: the kernel tells a loaded group from
         // an idle lane's eight sentinels by that slot alone
         for (uint32_t l = 0; l < G; ++l) {
