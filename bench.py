@@ -69,14 +69,37 @@ UNPINNED = ["reference put (storage.c:398-473 needs search_tree.c, i.e. ruby.h: 
             "vectors frozen in tests/golden/normalize_vectors.json)"]
 
 
+def code_only(text):
+    """C++ source without its comments and with white space collapsed: what the compiler sees.  (String and
+    character literals are kept as they are -- an asm string may hold anything.)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_hash():
-    """sha256 over the sources the find path's kernels and their launch logic are built from: what a PMC profile
-    must have been taken at to describe this run."""
+    """sha256 over the CODE (comments and white space apart) of the sources the find path's kernels and their
+    launch logic are built from: what a PMC profile must have been taken at to describe this run."""
     import hashlib
     h = hashlib.sha256()
     for f in ("find_kernels.hip", "find_kernels.h", "device_index.hip", "device_index.h", "c_abi.hip"):
-        with open(os.path.join(ROOT, "blurrily_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "blurrily_amd", "csrc", f), "r", encoding="utf-8") as fh:
+            h.update(code_only(fh.read()).encode("utf-8"))
     return h.hexdigest()[:16]
 # LDS atomics: no-return ds_add_u32 lanes per second, whole chip, MEASURED (tools/micro/lds_atomic_rate.hip,
 # profiles/r02_lds_atomic_rate.txt: conflict-free addresses, find_kernel's residency; 6.97e12 with random

@@ -100,3 +100,15 @@ def test_options_set_and_get():
     with pytest.raises(OSError):
         set_process_option("ws_cmin", 2)                        # a per-map key is not a process option
     m.close(); other.close()
+
+
+def test_the_profile_stamp_follows_the_code_not_the_comments():
+    """bench.py stamps PMC profiles with a hash of the kernel and launch sources and calls a profile stale when it
+    differs: a comment or a reflowed line must not, an edited token must."""
+    import bench
+    src = 'int f(int a) {  // adds one\n  /* really */ return a + 1;\n}\nconst char* s = "// kept";\n'
+    same = 'int f(int a) {\n  return a   + 1;  // reworded\n}\n\nconst char* s = "// kept"; /* new */\n'
+    other = src.replace("a + 1", "a + 2")
+    assert bench.code_only(src) == bench.code_only(same) != bench.code_only(other)
+    assert '"// kept"' in bench.code_only(src)
+    assert len(bench.kernel_source_hash()) == 16

@@ -38,14 +38,10 @@ def totals(dirpath):
 
 
 def kernel_source_hash():
-    """bench.py's: sha256 over the kernel and launch sources this profile was taken at."""
-    import hashlib
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for f in ("find_kernels.hip", "find_kernels.h", "device_index.hip", "device_index.h", "c_abi.hip"):
-        with open(os.path.join(root, "blurrily_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """bench.py's: sha256 over the code (comments apart) of the kernel and launch sources this profile was taken at."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_source_hash()
 
 
 def main():
