@@ -715,6 +715,19 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
                     STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
 }
 
+// The pool is compacted -- and the threshold tightened: it moves only there -- when it holds more than this many keys.
+// Capacity is for the rare flood (the first window's ties: an overflow costs a second sweep of the step); the
+// TRIGGER is what keeps the threshold tight, and with it the bounds the steps scan with and the keys they harvest.
+// It sat at half the capacity (256 keys at limit 10) through round 3; at `keep` and a half (16 keys at limit 10)
+// configs[2] takes 253 ms per 500 k needles instead of 279.5 -- and 73.5 instead of 93.7 ms per 200 k at limit 1,
+// 127.6 instead of 136.9 at limit 100 (tools/limit_probe.py).  12 to 20 keys measure alike at limit 10, 10 (a
+// compaction behind every admission) 2 % worse, 32 / 48 keys 1.7 / 3 % worse.  The same through a smaller POOL (64 keys)
+// cost configs[1] a hundred times the second sweeps.  Phase 1 of the window-major sweep keeps the old trigger: its one
+// step per needle floods by design (configs[4]: 68.7 vs 69.3 ms).
+__device__ __forceinline__ uint32_t select_at(const FindArgs& A) {
+  return A.own_only ? A.pool_cap / 2 : min(A.keep + max(6u, A.keep / 2), A.pool_cap / 2);
+}
+
 // ---- select: keep the pool small and the threshold tight.  Returns true when the pool
 // overflowed during the scan of this window, i.e. the window has to be swept again.
 template <int NT>
@@ -725,7 +738,7 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
   const uint32_t pn = ctl->pool_n;
   // compact when the pool fills up -- or as soon as it holds `keep` candidates for the first
   // time, so that a threshold exists from then on
-  if (!(ov || pn > A.pool_cap / 2 || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
+  if (!(ov || pn > select_at(A) || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
   if (STATS(A) && threadIdx.x == 0) atomicAdd(&STATS(A)[kStatCompactions], 1ull);
   compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
   PATH_FLAG(A, q_flag, ov ? kPathCompaction | kPathResweep : kPathCompaction);
@@ -1252,6 +1265,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // a threshold exists (it is set by compact_pool only, i.e. outside the hot loop below: re-read behind every exit)
   bool have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
   const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
+  const uint32_t sel_at = select_at(A);
   __syncthreads();
   uint2 h_next = ring->hdr[0];                                   // header of the step about to start ...
   uint4 pre_v = make_uint4(0, 0, 0, 0);                          // the wave's first unit of the next step, loaded ahead
@@ -1305,7 +1319,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // 2 % slower, 293.0 vs 287.2 ms per 500 k needles; the thresholds the headers carry are a step staler.)
       const uint2 c_ = *reinterpret_cast<const uint2*>(&ctl->pool_n);          // pool_n, overflow
       const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x), ov_ = __builtin_amdgcn_readfirstlane(c_.y);
-      if (ov_ != 0 || pn_ > A.pool_cap / 2 || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
+      if (ov_ != 0 || pn_ > sel_at || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
     }
     if (left == kLeftDone) break;
     // ---- the rare paths of step p ----------------------------------------------------------------
