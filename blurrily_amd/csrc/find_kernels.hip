@@ -1069,7 +1069,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   uint4* const cnt128 = reinterpret_cast<uint4*>(cnt32);
   const uint32_t ring_units = ring_units_for(A.pool_cap), ring_rows = ring_units / kNW;   // rows: units of a wave
   // (the i-th step visited: upward from the needle's own length class, round the end.  Outward from it instead --
-  // one step above, one below, by turns -- measured in round 3: 270.0 vs 253.2 ms per 500 k needles, 6.7 % slower)
+  // one step above, one below, by turns -- measured in round 3: 270.0 vs 253.2 ms per 500 k needles, 6.7 % slower;
+  // downward from it, round the start: 292.7 ms, 16 % slower -- every window visited later lies BEHIND the threshold's
+  // rank when the sweep goes upward, and needs one match more)
 #define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
   // most trigrams of the needle a reference of the step's window(s) can hold
 #define BLURRILY_WMT_AT(i_, out_)                                                \
