@@ -177,7 +177,9 @@ __global__ void tokenise_kernel(const char* __restrict__ packed, const uint64_t*
   }
   for (; k4 < d; ++k4) nb += code_total[out[k4]];
   q_ntri[q] = d;
-  q_start[q] = start_win[len < 255 ? len : 255];   // where references as long as the needle live
+  // where references as long as the needle live (the sweep's first window; one or two length classes earlier or
+  // later measured in round 3: +1 ... +4 % each way)
+  q_start[q] = start_win[len < 255 ? len : 255];
   q_nb[q] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
   if (d > 127) big_list[atomicAdd(big_count, 1u)] = q;            // 16-bit counters
   else if (d > 64) mid_list[atomicAdd(mid_count, 1u)] = q;        // byte counters, two table slots per lane
