@@ -738,7 +738,7 @@ __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned lo
   (void)q_flag;
   const uint32_t ov = ctl->overflow;
   const uint32_t pn = ctl->pool_n;
-  // compact when the pool fills up -- or as soon as it holds `keep` candidates for the first
+  // compact when the pool holds more than select_at() keys -- or as soon as it holds `keep` candidates for the first
   // time, so that a threshold exists from then on
   if (!(ov || pn > select_at(A) || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
   if (STATS(A) && threadIdx.x == 0) atomicAdd(&STATS(A)[kStatCompactions], 1ull);
@@ -1280,7 +1280,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   uint4 pre_v = make_uint4(0, 0, 0, 0);                          // the wave's first unit of the next step, loaded ahead
   uint32_t pre_h = 0;
   bool pre_live = false, pre_valid = false;
-  uint2 d_mine = BLURRILY_MY_UNITS(0u);  // ... and this wave's first unit of it
+  uint2 d_mine = BLURRILY_MY_UNITS(0u);  // ... and this wave's units of it (lane j: its j-th)
 
   // The sweep is a HOT LOOP of steps that need nothing special -- header, units, turns, barrier, scan with the
   // published bound, barrier, a glance at the pool -- and is left for everything else (more units than the ring
