@@ -25,6 +25,11 @@ extern "C" {
 
 /* ---------------------------------------------------------------- types ---- */
 
+/* When the reference's own ext/blurrily/storage.h has been included first (a translation unit of the gem's
+ * glue, ruby/ext/blurrily/map_ext_batch.c), its types are the types: this header then only RE-DECLARES the nine
+ * functions -- which the compiler checks for compatibility, tests/test_header_compat.py -- and adds part 2. */
+#ifndef __STORAGE_H__
+
 struct trigram_map_t;                               /* opaque; storage.h:15-16 */
 typedef struct trigram_map_t* trigram_map;
 
@@ -42,6 +47,8 @@ typedef struct trigram_stat_t {
   uint32_t references;
   uint32_t trigrams;
 } trigram_stat_t;
+
+#endif /* __STORAGE_H__ */
 
 /* ------------------------------------------------- part 1: reference ABI ---- */
 
