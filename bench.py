@@ -38,8 +38,14 @@ Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carr
                  prefix of the step's needles, whose rows are compared with the rows the GPU wrote
                  for the same needles in the timed launch: `parity_checked` needles, exit status 1
                  on any difference.
-  extra_configs  (N=1, default workload) configs[1] and configs[4] of BASELINE.json, a few steps
-                 each, same fields.
+  extra_configs  (N=1, default workload) configs[1] and configs[4] of BASELINE.json, then two further
+                 points on configs[2]'s kind of haystack: `geonames_x4` -- four times the strings, an
+                 image seven times the 256 MiB Infinity Cache, i.e. the one point whose bytes are HBM
+                 bytes -- and `geonames_miss` -- needles from a foreign vocabulary, without a close
+                 match, so that the threshold stays low.  A few steps each, same fields.
+
+A leg that fails -- the CPU baseline, an extra config, a parity comparison -- is recorded in the line
+AND makes the exit status 1: a line without its baseline is not a result.
 """
 import argparse
 import ctypes as C
@@ -56,6 +62,8 @@ for _p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (imported before the HIP library so both share one HIP runtime)
 
+PARITY_FLOOR = 32              # needles of every benched config compared row for row with the reference in the run
+INFINITY_CACHE_BYTES = 256 << 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0    # the same guide: 6.29 TB/s measured (float4 copy, 79 % of the spec)
 # what READS alone reach on this chip the way the kernel's units arrive -- pseudo-random 1 KiB per wave and load, 2 x
@@ -108,6 +116,9 @@ def kernel_source_hash():
 LDS_ATOMIC_PEAK_LANES = 9.34e12
 
 
+EXTRA_CONFIGS = ("words", "skewed", "geonames_x4", "geonames_miss")
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -149,6 +160,10 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s, gpu_rows, gpu_counts)
     if Reference.available():
         kind = "reference"
         path = f"/tmp/blurrily_bench_{os.getpid()}.trigrams"
+        import shutil
+        want = 12 * int(m.stats()["trigrams"]) + (64 << 20)       # the file: 8 B per slot, growth slack, page padding
+        if shutil.disk_usage("/tmp").free < want:
+            raise RuntimeError(f"/tmp has less than {want >> 20} MiB free for the reference's .trigrams file")
         m.save(path)
         ref = Reference(path)
         S = Reference.shim()
@@ -179,7 +194,8 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s, gpu_rows, gpu_counts)
     run(0, 1)                                        # page the index in
     k = min(4, len(raw))
     per = run(0, k) / k
-    n = int(max(k, min(len(raw), budget_s / max(per, 1e-7))))
+    # at least PARITY_FLOOR needles whatever the budget: the rows of the timed launch are compared on all of them
+    n = int(max(min(PARITY_FLOOR, len(raw)), min(len(raw), budget_s / max(per, 1e-7))))
     dt = run(0, n)
     # ---- parity of the timed GPU launch against these very rows ---------------------------------
     mismatches = []
@@ -329,13 +345,16 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     sum_nb, sum_rows = int(nb.sum()), int(gpu_counts.astype(np.int64).sum())
     algo_bytes = 8 * sum_nb + 8 * sum_T + 12 * sum_rows + 4 * n_q            # SURVEY.md 8(d), one launch
     k_ms = float(np.mean(kernel_ms))
+    sweeps = {0: "latency mode / long needles only", 1: "needle-major", 2: "window-major"}
+    sweep = sweeps[m.get_option("last_sweep")]                               # of the timed launches
     # one more launch, untimed, with the kernels' own request counters on: the physical bytes and the
-    # LDS-atomic lanes of exactly this batch
+    # LDS-atomic lanes of exactly this batch -- by the SAME sweep (a measured choice is kept while counting)
     m.set_stats(True)
     find()
     torch.cuda.synchronize()
     st = m.find_stats()
     m.set_stats(False)
+    counted_sweep = sweeps[m.get_option("last_sweep")]
     stats_rows_equal = bool(np.array_equal(gpu_counts, block.counts.cpu().numpy().view(np.uint32)))
     out_bytes = 12 * sum_rows + 4 * n_q + 4 * n_q                              # rows + counts + nb_entries
     needle_bytes = int(qo[-1]) + 8 * (n_q + 1) + 2 * (int(qo[-1]) + n_q)       # needles, offsets, code scratch (w+r)
@@ -432,6 +451,13 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # in-kernel (blurrily_storage_set_stats) in an extra untimed launch of THIS run; L2 hits included
                 "bound": "hbm", "achieved": req_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": req_gbs / HBM_PEAK_GBS,
+                # what the bytes of `frac` are: requests on the memory side of the L2.  Whether they are HBM bytes
+                # depends on the image: one several times the 256 MiB Infinity Cache leaves it little to carry
+                # (extra_configs.geonames_x4: 7 x), one of about its size (configs[2]) a good part
+                "bound_scope": ("HBM: the resident image is %.1f x the Infinity Cache" % (info["device_bytes"] / INFINITY_CACHE_BYTES)
+                                if info["device_bytes"] >= 4 * INFINITY_CACHE_BYTES else
+                                "memory side of L2 = HBM + Infinity Cache: the resident image is %.1f x the 256 MiB cache, "
+                                "which carries part of the traffic" % (info["device_bytes"] / INFINITY_CACHE_BYTES)),
                 # against what a streaming copy reaches on this chip (the guide's measured figure) -- meaningful where
                 # the requests miss the caches (configs[2]: L2 hit rate 6 %, index > Infinity Cache), an upper bound
                 # where they do not
@@ -448,10 +474,11 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # requests DESTINED for local DRAM at the fabric interface, i.e. still in front of the 256 MiB cache
                 "hbm_only_frac": None,
                 "hbm_only_note": "no DRAM-only byte counter on gfx950 (TCC_EA0_RDREQ_DRAM = requests destined for DRAM, "
-                                 "counted before the Infinity Cache); the 470 MB index exceeds the 256 MiB cache",
+                                 "counted before the Infinity Cache); see bound_scope and extra_configs.geonames_x4",
                 "kernel_source_hash": kernel_source_hash(),
-                "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if st["probes"] else
-                           "find_kernel<uint8_t,1024>"),
+                "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
+                           else "find_kernel<uint8_t,1024>" + (" (slices left out, settled by bitmap)" if st["probes"] else "")),
+                "sweep": sweep, "counted_sweep": counted_sweep,
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_gbs": algo_bytes / (k_ms * 1e-3) / 1e9,
@@ -477,13 +504,24 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             out["gather_bytes_per_rank"] = int(block.buf.numel() * 4)
             out["gather_overlapped"] = True     # gather_ms = what a step saw of the collective (issue + waits)
             out["gather_checked"] = gather_checked
+        if not stats_rows_equal:
+            log(f"PARITY: the counted launch of '{name}' wrote other rows than the timed one")
+            parity_ok = False
+        if counted_sweep != sweep:
+            log(f"the counted launch of '{name}' took the {counted_sweep} sweep, the timed ones the {sweep} sweep: "
+                f"the roofline block does not describe what was timed")
+            parity_ok = False
         if world == 1 and cpu_budget > 0:
             try:
+                if name == getattr(args, "inject_failure", None):
+                    raise RuntimeError("injected failure (--inject-failure)")
                 out["cpu_baseline"] = cpu_baseline(m, hay, hay_off, qp, qo, limit, cpu_budget, gpu_rows, gpu_counts)
-                parity_ok = out["cpu_baseline"]["parity_mismatches"] == 0
+                parity_ok = parity_ok and out["cpu_baseline"]["parity_mismatches"] == 0
                 out["parity_checked"] = out["cpu_baseline"]["parity_checked"]
-            except Exception as e:  # the GPU numbers stand on their own
-                out["cpu_baseline"] = {"error": str(e)}
+            except Exception as e:  # the line is still printed -- with the error, and the run exits 1
+                log(f"cpu_baseline of '{name}' FAILED: {e!r}")
+                out["cpu_baseline"] = {"error": repr(e)}
+                parity_ok = False
     m.close()
     return out, parity_ok
 
@@ -501,6 +539,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--latency-probes", type=int, default=200)
+    ap.add_argument("--inject-failure", default=None, metavar="WORKLOAD",
+                    help="(tests) make that workload's cpu_baseline leg raise: the line must carry the error and the exit status be 1")
     ap.add_argument("--static-choice", action="store_true",
                     help="the sweep by the static rule, not by measuring both on the first batch (PMC passes: "
                          "every find call of the run then launches the same kernels)")
@@ -539,7 +579,7 @@ def main():
                            args.latency_probes)
     if world == 1 and args.workload is None and not args.no_extra:
         extra = {}
-        for name in ("words", "skewed"):
+        for name in EXTRA_CONFIGS:
             try:
                 line, ok_x = run_workload(name, args, max(3, min(args.steps, 10)), 1, rank, local_rank, world, dist,
                                           min(budget, 4.0), min(args.latency_probes, 50))
@@ -547,8 +587,11 @@ def main():
                 extra[name] = {k: line[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "p50_query_us",
                                                     "matched_entries_per_sec", "entries_per_query", "kernel_ms",
                                                     "roofline", "cpu_baseline", "parity_checked") if k in line}
-            except Exception as e:
-                extra[name] = {"error": str(e)}
+            except Exception as e:                   # recorded, and the run exits 1
+                import traceback
+                log(f"extra config '{name}' FAILED:\n{traceback.format_exc()}")
+                extra[name] = {"error": repr(e)}
+                ok = False
         out["extra_configs"] = extra
     if world > 1:
         dist.barrier()

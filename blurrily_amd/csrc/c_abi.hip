@@ -75,8 +75,25 @@ struct PendingPut {
   uint32_t    weight;
 };
 
+struct trigram_map_t;
+// "devices" > 1: one more copy of the map's device side, on another visible device (or, with more replicas than
+// devices, on one that already has one): clones of the primary's images, a map object of its own for the scratch
+// buffers, events and measured choices its finds need, a stream, and staging for its shard of a batch.
+struct Replica {
+  int            device = -1;
+  trigram_map_t* side = nullptr;        // dev / delta / d_code_total_now are the clones; host == nullptr; mirror_of = the primary
+  uint64_t       base_builds = 0, delta_image_version = 0, log_version = 0;   // the primary's, as of the clones
+  hipStream_t    stream = nullptr;
+  hipEvent_t     ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  DeviceBuffer   d_in, d_out;           // [offsets | needles] of the batch, [rows | counts | nb_entries] of its shard
+};
+
 struct trigram_map_t {
   HostIndex*  host = nullptr;
+  const trigram_map_t* mirror_of = nullptr;   // a replica's side map: the mutation log that counts is this map's
+  std::vector<Replica> replicas;        // "devices" - 1 of them
+  uint32_t    n_devices = 1;            // option "devices": shards of a large batch (the primary's included)
+  hipEvent_t  ev_ready = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;   // multi-device batches
   DeviceIndex dev;                      // base image
   // log of puts/deletes the base image does not contain yet
   std::unordered_map<uint32_t, PendingPut> pending;   // by reference
@@ -96,12 +113,16 @@ struct trigram_map_t {
   // tunables of the window-major sweep (blurrily_storage_set_option; defaults from the measured gate)
   IndexBuildOptions build_opt;          // ws_enabled, ws_min_windows, ws_min_slice, dense_min
   uint32_t    ws_cmin = 3;              // a left-out slice must leave at least this many counted matches
+  uint32_t    nm_cmin = 3;              // the same for the needle-major sweep (0: it leaves nothing out)
+  uint32_t    nm_dense = 4096;          // ... which leaves out slices of at least this many postings only
   uint32_t    ws_min_needles = 16384;   // smaller batches: needle-major
   bool        ws_autotune = true;       // measure the choice per class of batch on first use (run_find_on)
   uint32_t    ws_static_slice = 2200;   // the static rule's mean_hit_slice (autotune off): break-even of the skewed family
   int         ws_choice[6] = {0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major
   float       ws_tuned_ms[6][2] = {};   // what the measurement saw (needle-major, window-major)
-  hipEvent_t  tune_ev[3] = {nullptr, nullptr, nullptr};
+  int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2; 0: neither yet)
+  size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
+  hipEvent_t  tune_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int         n_cus = 0;
   bool        timing = false;
   bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
@@ -141,17 +162,16 @@ void clear_log(trigram_map m) {
   m->delta_host = nullptr;
 }
 
-bool log_empty(const trigram_map m) { return m->pending.empty() && m->n_tomb == 0 && !m->log_overflow; }
+// (a replica's side map holds clones of the images; the log they were cloned at is the primary's)
+const trigram_map_t* log_of(const trigram_map_t* m) { return m->mirror_of ? m->mirror_of : m; }
+bool log_empty(const trigram_map_t* m) { const trigram_map_t* l = log_of(m); return l->pending.empty() && l->n_tomb == 0 && !l->log_overflow; }
 
 // Bring the device side up to date with the host index.  Small logs are served by a delta
 // image (built from the pending puts only) plus tombstones on the base image; a log past
 // 1/64 of the base (or 4096 mutations) triggers a full rebuild.
 int ensure_device(trigram_map m) {
   const bool have_base = m->dev.device >= 0;
-  // (an option changed so that the window-major sweep may now run on an image built without bitmaps: rebuild)
-  const bool lacks_bitmaps = have_base && !m->dev.d_bm_id &&
-                             m->build_opt.wants_bitmaps(m->dev.n_windows, m->dev.mean_hit_slice);
-  if (!have_base || lacks_bitmaps || m->log_overflow || m->pending.size() + m->n_tomb > log_budget(m)) {
+  if (!have_base || m->log_overflow || m->pending.size() + m->n_tomb > log_budget(m)) {
     if (device_index_build(*m->host, &m->dev, m->build_opt) < 0) return -1;
     ++m->base_builds;
     std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);     // a new image: measure again
@@ -254,6 +274,8 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
                 hipStream_t stream) {
   if (n == 0) return 0;
   if (n > 0xFFFFFFF0ull) { errno = EINVAL; return -1; }
+  const bool is_base = &ix == &m->dev;                 // (the delta image of pending puts is searched the same way)
+  if (is_base) m->last_sweep = 0;
 
   // scratch: codes | per-needle arrays | scalars
   const size_t code_slots = packed_bytes + n;
@@ -291,6 +313,9 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   a.q_ntri = q_ntri; a.q_nb = q_nb; a.q_start = q_start; a.win_max_tri = ix.d_win_max_tri; a.nib_windows = ix.nib_windows; a.results = d_results; a.counts = d_counts; a.limit = limit;
   a.floor = floor;
   a.tomb = d_tomb;
+  a.dense_min8 = ix.dense_min8;
+  a.nm_dense = std::max((m->nm_dense + 7u) & ~7u, ix.dense_min8);
+  a.nm_cmin = m->nm_cmin;
   a.stats = m->collect_stats ? m->d_stats : nullptr;
   const bool cb = a.stats != nullptr;
   if (cb) {                                          // wave 0's phase clocks per workgroup (counted build only)
@@ -354,7 +379,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     auto run_ws = [&]() -> int {
       a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
       a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
-      a.bm_id = ix.d_bm_id; a.bitmaps = ix.d_bitmaps; a.cmin = m->ws_cmin;
+      a.cmin = m->ws_cmin;
       // Phase 1: the needle-major kernel over the window pair of every needle's own length class seeds the
       // states (a needle's best matches live there, so its threshold is tight before the other windows are
       // visited).  (Seeding through wsweep_kernel's own robust path instead -- own_pass launches -- was
@@ -378,7 +403,6 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         if (!(a.queue = next_queue())) { errno = EIO; return -1; }
         if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
       }
-      a.bm_id = nullptr; a.bitmaps = nullptr;
       return 0;
     };
     // needles with <= 127 distinct trigrams, needle-major: byte counters, up to 1024 rows per pass
@@ -409,35 +433,58 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // them, once), and the faster one serves that class until the image is rebuilt or an option changes.  With
     // "ws_autotune" 0 (or while request counters are collected) the static rule of the measured table applies.
     bool use_ws = false;
-    const bool ws_possible = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.d_bm_id != nullptr &&
-                             m->build_opt.wants_bitmaps(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
+    const bool ws_possible = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.n_bitmaps != 0 &&
+                             m->build_opt.ws_can_run(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
     if (ws_possible) {
-      const double slice_factor = (n < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
+      // (a chunk of a host-buffer batch belongs to the class of the WHOLE batch: class_hint)
+      const size_t n_cls = std::max(n, m->class_hint);
+      const double slice_factor = (n_cls < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
       const bool static_rule = ix.mean_hit_slice >= slice_factor * double(m->ws_static_slice);
-      const int cls = (limit > 32 ? 3 : 0) + (n < 65536 ? 0 : n < 262144 ? 1 : 2);
-      if (!m->ws_autotune || cb || &ix != &m->dev) {
+      const int cls = (limit > 32 ? 3 : 0) + (n_cls < 65536 ? 0 : n_cls < 262144 ? 1 : 2);
+      if (!m->ws_autotune || &ix != &m->dev) {
         use_ws = static_rule;
-      } else if (m->ws_choice[cls] == 0) {             // measure this class, once
-        if (!m->tune_ev[0])
-          for (auto& e : m->tune_ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
+      } else if (m->ws_choice[cls] != 0) {
+        use_ws = m->ws_choice[cls] == 2;
+      } else if (cb) {
+        use_ws = static_rule;                          // (counters must describe ONE sweep: an unmeasured class is not measured here)
+      } else {
+        // Measure this class, once: needle-major, window-major, needle-major AGAIN -- the first run of the three
+        // meets cold caches (the image's postings are about the size of the Infinity Cache) and pays whatever a
+        // first launch pays, so the needle-major figure is the better of its two runs; the window-major sweep is
+        // preferred only when it wins by 5 % (it pays one launch per window, and a tie is no reason for that).
+        if (!m->tune_ev[0]) {
+          hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+          for (auto& e : ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+              for (auto& d : ev) if (d) (void)hipEventDestroy(d);
+              errno = EIO;
+              return -1;
+            }
+          for (int i = 0; i < 4; ++i) m->tune_ev[i] = ev[i];
+        }
         BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[0], stream));
         if (run_nm() < 0) return -1;
         BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[1], stream));
         if (run_ws() < 0) return -1;
         BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[2], stream));
-        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[2]));
-        float nm_ms = 0.f, ws_ms = 0.f;
+        if (run_nm() < 0) return -1;
+        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[3], stream));
+        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[3]));
+        float nm_ms = 0.f, ws_ms = 0.f, nm2_ms = 0.f;
         BLURRILY_HIP_TRY(hipEventElapsedTime(&nm_ms, m->tune_ev[0], m->tune_ev[1]));
         BLURRILY_HIP_TRY(hipEventElapsedTime(&ws_ms, m->tune_ev[1], m->tune_ev[2]));
-        m->ws_choice[cls] = ws_ms < nm_ms ? 2 : 1;
+        BLURRILY_HIP_TRY(hipEventElapsedTime(&nm2_ms, m->tune_ev[2], m->tune_ev[3]));
+        nm_ms = std::min(nm_ms, nm2_ms);
+        m->ws_choice[cls] = ws_ms < 0.95f * nm_ms ? 2 : 1;
         m->ws_tuned_ms[cls][0] = nm_ms; m->ws_tuned_ms[cls][1] = ws_ms;
-        goto short_needles_done;                       // (both ran: the rows are there)
-      } else {
-        use_ws = m->ws_choice[cls] == 2;
+        m->last_sweep = 1;                             // (the rows in place are the needle-major run's; both give the same)
+        (void)is_base;
+        goto short_needles_done;
       }
     }
     if (ranges <= 1) {
       if ((use_ws ? run_ws() : run_nm()) < 0) return -1;
+      if (is_base) m->last_sweep = use_ws ? 2 : 1;
     }
   short_needles_done:
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
@@ -486,10 +533,10 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   uint32_t* base_counts = static_cast<uint32_t*>(m->ws_base_counts.p);
   trigram_match delta_rows = static_cast<trigram_match>(m->ws_delta_rows.p);
   uint32_t* delta_counts = static_cast<uint32_t*>(m->ws_delta_counts.p);
-  if (run_find_on(m, m->dev, m->d_code_total_now, m->n_tomb ? m->dev.d_tomb : nullptr, d_packed, packed_bytes,
+  if (run_find_on(m, m->dev, m->d_code_total_now, log_of(m)->n_tomb ? m->dev.d_tomb : nullptr, d_packed, packed_bytes,
                   d_offsets, n, limit, base_rows, base_counts, d_nb, maybe_long, maybe_mid, stream) < 0)
     return -1;
-  if (m->pending.empty()) {
+  if (log_of(m)->pending.empty()) {
     BLURRILY_HIP_TRY(hipMemsetAsync(delta_counts, 0, n * 4, stream));
   } else if (run_find_on(m, m->delta, m->delta.d_code_total, nullptr, d_packed, packed_bytes, d_offsets, n, limit,
                          delta_rows, delta_counts, nullptr, maybe_long, maybe_mid, stream) < 0) {
@@ -497,6 +544,190 @@ int run_find(trigram_map m, const char* d_packed, size_t packed_bytes, const uin
   }
   return launch_merge_rows(base_rows, base_counts, delta_rows, delta_counts, uint32_t(n), limit, d_results,
                            d_counts, stream);
+}
+
+// ---- "devices" > 1: the batch sharded over replicas of the device image, in ONE process -----------------------
+// (the drop-in host is a single process: the reference's server is one reactor, lib/blurrily/server.rb:19-30,
+// its glue one call at a time, ext/blurrily/map_ext.c:131-162 -- SURVEY.md section 8(e)'s partition, replicate and
+// shard contiguously, behind the C ABI instead of behind torch.distributed)
+
+void free_replica(Replica& r) {
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (r.device >= 0) (void)hipSetDevice(r.device);
+  if (r.stream) (void)hipStreamSynchronize(r.stream);
+  if (r.side) {
+    trigram_map s = r.side;
+    if (s->dev.device >= 0) device_index_free(&s->dev);
+    if (s->delta.device >= 0) device_index_free(&s->delta);
+    if (s->d_code_total_now) (void)hipFree(s->d_code_total_now);
+    if (s->d_stats) (void)hipFree(s->d_stats);
+    if (s->d_phase) (void)hipFree(s->d_phase);
+    s->ws_base_rows.release(); s->ws_base_counts.release(); s->ws_delta_rows.release(); s->ws_delta_counts.release();
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->tune_ev) if (e) (void)hipEventDestroy(e);
+    s->ws_codes.release(); s->ws_small.release(); s->ws_parts.release(); s->ws_flags.release(); s->ws_tomb.release();
+    delete s;
+  }
+  r.d_in.release(); r.d_out.release();
+  for (hipEvent_t e : {r.ev_done, r.ev_t0, r.ev_t1}) if (e) (void)hipEventDestroy(e);
+  if (r.stream) (void)hipStreamDestroy(r.stream);
+  r = Replica();
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+// Bring the replicas up to date with the primary's images (which ensure_device has just brought up to date with
+// the host index): device-to-device clones of whatever changed -- the base image after a rebuild, the delta image
+// when the set of pending puts changed, the tombstone bitmap and the bucket totals when anything was logged.
+int ensure_replicas(trigram_map m) {
+  int ndev = 0;
+  BLURRILY_HIP_TRY(hipGetDeviceCount(&ndev));
+  const size_t want = m->n_devices > 1 ? m->n_devices - 1 : 0;
+  while (m->replicas.size() > want) { free_replica(m->replicas.back()); m->replicas.pop_back(); }
+  while (m->replicas.size() < want) {
+    Replica r;
+    // replica k lives on the k-th device behind the primary's, round the visible ones (more replicas than devices --
+    // the tests' way of running the multi-device path on one GPU -- share devices)
+    r.device = (m->dev.device + 1 + int(m->replicas.size())) % ndev;
+    r.side = new (std::nothrow) trigram_map_t();
+    if (!r.side) { errno = ENOMEM; return -1; }
+    r.side->mirror_of = m;
+    DeviceScope on(r.device);
+    if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&r.ev_t0) != hipSuccess || hipEventCreate(&r.ev_t1) != hipSuccess) {
+      free_replica(r);
+      errno = EIO;
+      return -1;
+    }
+    m->replicas.push_back(r);
+  }
+  if (!m->ev_ready) {
+    BLURRILY_HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
+    BLURRILY_HIP_TRY(hipEventCreate(&m->ev_t0));
+    BLURRILY_HIP_TRY(hipEventCreate(&m->ev_t1));
+  }
+  for (Replica& r : m->replicas) {
+    trigram_map s = r.side;
+    // options and measured choices follow the primary's
+    s->build_opt = m->build_opt; s->ws_cmin = m->ws_cmin; s->nm_cmin = m->nm_cmin; s->nm_dense = m->nm_dense;
+    s->ws_min_needles = m->ws_min_needles; s->ws_autotune = m->ws_autotune; s->ws_static_slice = m->ws_static_slice;
+    for (int c = 0; c < 6; ++c) if (m->ws_choice[c]) s->ws_choice[c] = m->ws_choice[c];
+    s->n_cus = 0;
+    if (r.base_builds != m->base_builds || s->dev.device < 0) {
+      if (device_index_clone(m->dev, r.device, &s->dev) < 0) return -1;
+      std::fill(std::begin(s->ws_choice), std::end(s->ws_choice), 0);
+      for (int c = 0; c < 6; ++c) s->ws_choice[c] = m->ws_choice[c];
+      r.base_builds = m->base_builds;
+      r.log_version = ~0ull;                                   // (tombstones and totals below)
+      r.delta_image_version = ~0ull;
+    }
+    if (s->n_cus == 0) {
+      hipDeviceProp_t prop;
+      BLURRILY_HIP_TRY(hipGetDeviceProperties(&prop, r.device));
+      s->n_cus = prop.multiProcessorCount;
+    }
+    if (r.delta_image_version != m->delta_image_version) {
+      if (m->delta.device < 0) { if (s->delta.device >= 0) device_index_free(&s->delta); }
+      else if (device_index_clone(m->delta, r.device, &s->delta) < 0) return -1;
+      r.delta_image_version = m->delta_image_version;
+    }
+    if (r.log_version != m->log_version) {
+      DeviceScope on(r.device);
+      BLURRILY_HIP_TRY(hipMemcpyPeer(s->dev.d_tomb, r.device, m->dev.d_tomb, m->dev.device,
+                                     ((size_t(m->dev.n_refs) + 31) / 32 + 1) * sizeof(uint32_t)));
+      if (m->d_code_total_now) {
+        if (!s->d_code_total_now)
+          BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_code_total_now), kNumCodes * sizeof(uint32_t)));
+        BLURRILY_HIP_TRY(hipMemcpyPeer(s->d_code_total_now, r.device, m->d_code_total_now, m->dev.device,
+                                       kNumCodes * sizeof(uint32_t)));
+      }
+      r.log_version = m->log_version;
+    }
+  }
+  return 0;
+}
+
+// n device-resident needles on the primary's device, results into buffers there, the work sharded contiguously over
+// the primary and its replicas: every replica gets the batch's needles by ONE peer copy, searches its shard on its own
+// stream and sends its block of rows (and counts, nb_entries) straight into the caller's buffers by peer copies --
+// the gather of SURVEY.md section 8(e), point to point over xGMI.  Everything is enqueued: `stream` waits for the
+// replicas' events, the host for nothing (timing mode apart).
+int run_find_multi(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
+                   uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, hipStream_t stream) {
+  if (apply_tombstones(m, stream) < 0) return -1;             // (the bits are set before the replicas copy the bitmap)
+  if (ensure_replicas(m) < 0) return -1;
+  const size_t R = m->replicas.size() + 1;
+  const int P = m->dev.device;
+  BLURRILY_HIP_TRY(hipEventRecord(m->ev_ready, stream));      // the caller's needles are in place behind this
+  const bool timing = m->timing;
+  auto bound = [&](size_t r) { return n * r / R; };
+  const size_t off_bytes = align_up((n + 1) * sizeof(uint64_t), 256);
+  for (size_t k = 0; k + 1 < R; ++k) {
+    Replica& r = m->replicas[k];
+    const size_t a = bound(k + 1), b = bound(k + 2), c = b - a;
+    if (c == 0) continue;
+    DeviceScope on(r.device);
+    const size_t cnt_bytes = align_up(c * sizeof(uint32_t), 256);
+    const size_t row_bytes = align_up(std::max<size_t>(c * size_t(limit) * sizeof(trigram_match_t), 16), 256);
+    if (r.d_in.reserve(off_bytes + std::max<size_t>(packed_bytes, 16), r.stream) < 0 ||
+        r.d_out.reserve(row_bytes + 2 * cnt_bytes, r.stream) < 0)
+      return -1;
+    unsigned char* in = static_cast<unsigned char*>(r.d_in.p);
+    unsigned char* out = static_cast<unsigned char*>(r.d_out.p);
+    BLURRILY_HIP_TRY(hipStreamWaitEvent(r.stream, m->ev_ready, 0));
+    BLURRILY_HIP_TRY(hipMemcpyPeerAsync(in, r.device, d_offsets, P, (n + 1) * sizeof(uint64_t), r.stream));
+    if (packed_bytes)
+      BLURRILY_HIP_TRY(hipMemcpyPeerAsync(in + off_bytes, r.device, d_packed, P, packed_bytes, r.stream));
+    trigram_match rows = reinterpret_cast<trigram_match>(out);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(out + row_bytes);
+    uint32_t* nb = reinterpret_cast<uint32_t*>(out + row_bytes + cnt_bytes);
+    r.side->timing = false;
+    r.side->collect_stats = false;
+    if (timing) BLURRILY_HIP_TRY(hipEventRecord(r.ev_t0, r.stream));
+    // (the shard's offsets are the batch's own, from its first needle on: they index the whole needle buffer)
+    if (run_find(r.side, reinterpret_cast<const char*>(in + off_bytes), packed_bytes,
+                 reinterpret_cast<const uint64_t*>(in) + a, c, limit, rows, counts, d_nb ? nb : nullptr, true, true,
+                 r.stream) < 0)
+      return -1;
+    if (timing) BLURRILY_HIP_TRY(hipEventRecord(r.ev_t1, r.stream));
+    if (limit)
+      BLURRILY_HIP_TRY(hipMemcpyPeerAsync(d_results + a * size_t(limit), P, rows, r.device,
+                                          c * size_t(limit) * sizeof(trigram_match_t), r.stream));
+    BLURRILY_HIP_TRY(hipMemcpyPeerAsync(d_counts + a, P, counts, r.device, c * sizeof(uint32_t), r.stream));
+    if (d_nb) BLURRILY_HIP_TRY(hipMemcpyPeerAsync(d_nb + a, P, nb, r.device, c * sizeof(uint32_t), r.stream));
+    BLURRILY_HIP_TRY(hipEventRecord(r.ev_done, r.stream));
+  }
+  // the primary's own shard, on the caller's stream (its timing mode would wait for it: the replicas are under way)
+  const size_t c0 = bound(1);
+  m->timing = false;
+  if (timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev_t0, stream));
+  const int rc = run_find(m, d_packed, packed_bytes, d_offsets, c0, limit, d_results, d_counts, d_nb, true, true, stream);
+  m->timing = timing;
+  if (rc < 0) return -1;
+  if (timing) BLURRILY_HIP_TRY(hipEventRecord(m->ev_t1, stream));
+  for (size_t k = 0; k + 1 < R; ++k)
+    if (bound(k + 2) > bound(k + 1)) BLURRILY_HIP_TRY(hipStreamWaitEvent(stream, m->replicas[k].ev_done, 0));
+  if (timing) {                                               // last_find_kernel_ms: the slowest shard's search
+    BLURRILY_HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f, worst = 0.f;
+    BLURRILY_HIP_TRY(hipEventElapsedTime(&worst, m->ev_t0, m->ev_t1));
+    for (size_t k = 0; k + 1 < R; ++k) {
+      if (bound(k + 2) == bound(k + 1)) continue;
+      DeviceScope on(m->replicas[k].device);
+      BLURRILY_HIP_TRY(hipEventElapsedTime(&ms, m->replicas[k].ev_t0, m->replicas[k].ev_t1));
+      worst = std::max(worst, ms);
+    }
+    m->last_find_ms = worst;
+    m->last_tok_ms = 0.0;
+  }
+  return 0;
+}
+
+// a batch goes over the replicas when "devices" asks for them and it is big enough to be worth a peer copy per
+// device (and no request counters are being collected: they describe one launch sequence)
+bool wants_multi(const trigram_map_t* m, size_t n) {
+  return m->n_devices > 1 && !m->collect_stats && n >= size_t(1024) * m->n_devices;
 }
 
 }  // namespace
@@ -526,6 +757,9 @@ int blurrily_storage_close(trigram_map* haystack) {
   trigram_map m = *haystack;
   if (m) {
     DeviceScope scope(m->dev.device);
+    for (Replica& r : m->replicas) free_replica(r);
+    m->replicas.clear();
+    for (hipEvent_t e : {m->ev_ready, m->ev_t0, m->ev_t1}) if (e) (void)hipEventDestroy(e);
     if (m->dev.device >= 0) {
       (void)hipDeviceSynchronize();
       device_index_free(&m->dev);
@@ -619,6 +853,9 @@ int blurrily_storage_find_batch_device(trigram_map m, const char* d_packed, size
   if (ensure_device(m) < 0) return -1;
   if (m->timing && !m->ev[0])
     for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
+  if (wants_multi(m, n))
+    return run_find_multi(m, d_packed, packed_bytes, d_offsets, n, limit, d_results, d_counts, d_nb_entries,
+                          static_cast<hipStream_t>(stream));
   return run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_results, d_counts, d_nb_entries, true,
                   true, static_cast<hipStream_t>(stream));
 }
@@ -729,7 +966,9 @@ static int find_batch_chunked_run(trigram_map m, const char* packed, const uint6
 
 static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                               trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii, size_t chunk) {
+  m->class_hint = n;
   const int rc = find_batch_chunked_run(m, packed, offsets, n, limit, results, counts, raw, non_ascii, chunk);
+  m->class_hint = 0;
   if (rc < 0) {                                       // chunks may still be in flight on the three streams: let them
     const int e = errno;                              // finish before anybody reuses the slots
     (void)hipDeviceSynchronize();
@@ -766,7 +1005,8 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
   if (m->timing && !m->ev[0])
     for (auto& e : m->ev) BLURRILY_HIP_TRY(hipEventCreate(&e));
   // (timing and request counters describe ONE launch sequence: those runs stay in one piece)
-  if (m->host_chunk && n >= 2 * size_t(m->host_chunk) && !m->timing && !m->collect_stats) {
+  const bool multi = wants_multi(m, n);   // (the batch then goes in one piece through the primary: its rows come home over ONE PCIe link)
+  if (!multi && m->host_chunk && n >= 2 * size_t(m->host_chunk) && !m->timing && !m->collect_stats) {
     size_t chunk = m->host_chunk;
     const size_t row_cap = size_t(32) << 20;                      // at most 32 MiB of rows per chunk in pinned staging
     while (chunk > 1024 && chunk * size_t(limit) * sizeof(trigram_match_t) > row_cap) chunk >>= 1;
@@ -807,8 +1047,9 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
                                       stream));
   }
   if (raw && launch_normalise(d_packed, d_offsets, uint32_t(n), d_packed, d_flags, stream) < 0) return -1;
-  if (run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_rows, d_counts, nullptr, max_len > 126,
-               max_len > 63, stream) < 0)
+  if ((multi ? run_find_multi(m, d_packed, packed_bytes, d_offsets, n, limit, d_rows, d_counts, nullptr, stream)
+             : run_find(m, d_packed, packed_bytes, d_offsets, n, limit, d_rows, d_counts, nullptr, max_len > 126,
+                        max_len > 63, stream)) < 0)
     return -1;
   if (staged) {
     unsigned char* h_out = m->h_stage + kStageBytes;
@@ -877,7 +1118,7 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
   info->n_tombstones = uint32_t(m->n_tomb);
   info->base_builds = m->base_builds;
   info->mean_hit_slice = m->dev.mean_hit_slice;
-  info->n_bitmaps = m->dev.d_bm_id ? m->dev.n_bitmaps : 0;
+  info->n_bitmaps = m->dev.n_bitmaps;
   info->reserved_ = 0;
   info->dense_share = m->dev.dense_share;
   info->ws_gain = m->dev.ws_gain;
@@ -895,7 +1136,8 @@ struct OptionSlot { const char* key; long long lo, hi; };
 constexpr OptionSlot kMapOptions[] = {
     {"wsweep", 0, 1}, {"ws_cmin", 1, 64}, {"ws_min_windows", 0, 1 << 20}, {"ws_min_needles", 0, 1ll << 32},
     {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}, {"host_chunk", 0, 1ll << 30},
-    {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0}};
+    {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0},
+    {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -928,6 +1170,10 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 7: m->ws_autotune = value != 0; break;
     case 8: m->ws_static_slice = uint32_t(value); break;
     case 9: break;                                       // (value 0 only: forget what was measured)
+    case 10: m->nm_cmin = uint32_t(value); break;
+    case 11: m->nm_dense = uint32_t(value); break;
+    case 12: m->last_sweep = 0; return 0;                // (value 0 only; nothing to measure again)
+    case 13: m->n_devices = uint32_t(value); return 0;   // (replicas are made, or dropped, by the next large batch)
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -957,6 +1203,10 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
       *value = v;
       return 0;
     }
+    case 10: *value = m->nm_cmin; return 0;
+    case 11: *value = m->nm_dense; return 0;
+    case 12: *value = m->last_sweep; return 0;
+    case 13: *value = m->n_devices; return 0;
     default: errno = EINVAL; return -1;
   }
 }

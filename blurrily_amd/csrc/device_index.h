@@ -20,8 +20,15 @@
 //     eight entries with the sentinel 0xFFFF (the one in-window rank no
 //     reference uses), so the kernel counts whole 16-byte groups without any
 //     range check; counter slot 0xFFFF is a scratch slot the scan ignores.
-//   * a slice with >= kDenseMin postings additionally exists as a bitmap over the window's ranks
-//     (bm_id[w * kNumCodes + t] -> bitmaps[id * kBitmapWords ..]); see find_kernels.hip, wsweep_kernel.
+//   * a DENSE slice -- at least dense_min8 entries, padding included -- additionally exists as a bitmap over the
+//     window's ranks, stored INLINE in `ent` in front of its postings: slice_off[] spans bitmap + postings, the
+//     first kBitmapSlots entries (8 KiB) are the bitmap (bit r set iff in-window rank r holds the code), the
+//     postings follow.  A kernel tells a dense slice by its span alone (span >= dense_min8: a slice that is not
+//     dense is shorter than that, a dense one at least kBitmapSlots longer), so there is no table of bitmap
+//     numbers to load, and every image carries the bitmaps of its dense slices (round 4; rounds 2-3 kept
+//     bm_id[] + bitmaps[] beside `ent`, only on images the window-major sweep could run on).  Both sweeps leave
+//     dense slices out of the count where the threshold allows and ask the bitmap about the few ranks that matter
+//     (find_kernels.hip: sweep_coop, wsweep_kernel).
 //   * code_total[t] = used[t] of the reference's bucket t (storage.c:501), for
 //     the matched-entries metric.
 //   * win_max_tri[w]: the largest number of postings (= distinct trigrams) any one
@@ -54,6 +61,7 @@ constexpr uint32_t kEntPad     = 64;   // u16 slack after the last entry (16-byt
 // leaves such slices out of the count and asks the bitmap about the few ranks that matter instead.
 constexpr uint32_t kDenseMin     = 1024;                // default of IndexBuildOptions::dense_min
 constexpr uint32_t kBitmapWords  = kWindowSize / 32;    // u32 words per bitmap
+constexpr uint32_t kBitmapSlots  = kWindowSize / 16;    // the same in 16-bit entries of `ent` (8 KiB: slices stay 16-byte aligned)
 constexpr uint32_t kNoBitmap     = 0xFFFFFFFFu;
 
 struct DeviceIndex {
@@ -74,9 +82,8 @@ struct DeviceIndex {
   uint32_t* d_win_max_tri    = nullptr;   // [n_windows] most postings any one reference of the window has
   uint32_t* d_start_win      = nullptr;   // [256] window holding the first rank whose weight is >= the index
   uint32_t* d_tomb           = nullptr;   // [(n_refs+31)/32] bit r: rank r was deleted after the build
-  uint32_t* d_bm_id          = nullptr;   // [n_windows * kNumCodes] bitmap number of a dense slice, else kNoBitmap
-  uint32_t* d_bitmaps        = nullptr;   // [n_bitmaps * kBitmapWords]
-  uint32_t  n_bitmaps        = 0;
+  uint32_t  n_bitmaps        = 0;         // dense slices (each starts with its bitmap, inline in d_ent)
+  uint32_t  dense_min8       = 0;         // a slice spanning at least this many entries is dense (a multiple of 8)
   // postings a needle's trigram finds in one window, on average, when needle trigrams are distributed
   // like the haystack's postings: (sum of used[t]^2 / sum of used[t]) / n_windows.  The window-major
   // sweep pays a fixed price per (needle, window) and saves in proportion to the postings it leaves
@@ -94,9 +101,9 @@ struct DeviceIndex {
   std::vector<uint32_t> h_rank_of_pos;    // rank of h_sorted_ref[i]
 };
 
-// What the window-major sweep needs of an image (blurrily_storage_set_option; c_abi.hip holds the per-map copy).
-// Bitmaps of dense slices cost host time, upload and HBM (Geonames scale: 143 MB + an 11 MB id table), so an
-// image gets them only when the sweep can run on it at all.
+// How an image is built and which of them the window-major sweep may be taken on (blurrily_storage_set_option;
+// c_abi.hip holds the per-map copy).  Every image carries the bitmaps of its dense slices (Geonames scale: 17 k of
+// them, 143 MB, inline in `ent`).
 struct IndexBuildOptions {
   bool     ws_enabled     = true;
   uint32_t ws_min_windows = 8;      // fewer windows: the needle-major sweep is taken whatever the batch
@@ -104,7 +111,7 @@ struct IndexBuildOptions {
                                     // below it the sweep lost on every haystack measured; above
                                     // it c_abi.hip MEASURES the choice per class of batch on first use
   uint32_t dense_min      = kDenseMin;
-  bool wants_bitmaps(uint32_t n_windows, double mean_hit_slice) const {
+  bool ws_can_run(uint32_t n_windows, double mean_hit_slice) const {
     return ws_enabled && n_windows >= ws_min_windows && mean_hit_slice >= double(ws_min_slice);
   }
 };
@@ -116,6 +123,9 @@ struct IndexBuildOptions {
 // buckets).
 int  device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuildOptions& opt = IndexBuildOptions());
 void device_index_free(DeviceIndex* ix);
+// A copy of `src` on HIP device `dst_device` (which may be src's own): device to device, nothing is rebuilt on the
+// host.  The copy holds no host-side reference table (deletes are mapped to ranks on the original).  0, or -1 + errno.
+int  device_index_clone(const DeviceIndex& src, int dst_device, DeviceIndex* out);
 // Rank of `ref` in the device image, or -1 if the image does not hold it.
 int64_t device_index_rank_of(const DeviceIndex& ix, uint32_t ref);
 

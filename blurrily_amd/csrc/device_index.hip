@@ -85,8 +85,6 @@ void device_index_free(DeviceIndex* ix) {
   if (ix->d_win_max_tri)    (void)hipFree(ix->d_win_max_tri);
   if (ix->d_start_win)      (void)hipFree(ix->d_start_win);
   if (ix->d_tomb)           (void)hipFree(ix->d_tomb);
-  if (ix->d_bm_id)          (void)hipFree(ix->d_bm_id);
-  if (ix->d_bitmaps)        (void)hipFree(ix->d_bitmaps);
   *ix = DeviceIndex();
 }
 
@@ -276,24 +274,25 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   if (failed.load()) { errno = EPROTO; return -1; }
   stage("rank postings");
 
-  // pad every slice to a multiple of eight entries (16 bytes), then prefix-sum; dense slices get a
-  // bitmap number (in slice order: the image does not depend on thread timing)
+  // pad every slice to a multiple of eight entries (16 bytes), a dense one gets its bitmap in front of its
+  // postings (device_index.h), then prefix-sum
   uint64_t n_slots = 0;
-  // (only when the window-major sweep can run on this image at all: no bitmaps, no id table otherwise)
   double mean_hit_slice = 0.0;
   {
     double sq = 0.0;
     for (uint32_t t = 0; t < kNumCodes; ++t) sq += double(code_total[t]) * double(code_total[t]);
     mean_hit_slice = nnz ? sq / double(nnz) / double(n_win) : 0.0;
   }
-  const uint32_t dense_min = std::max(64u, opt.dense_min);
+  // dense: the PADDED length reaches dense_min8 -- what a kernel can tell from the slice table alone
+  const uint32_t dense_min8 = (std::max(64u, std::min(opt.dense_min, kWindowSize)) + 7u) & ~7u;
+  auto is_dense = [&](uint32_t len) { return ((len + 7u) & ~7u) >= dense_min8; };
   double dense_share = 0.0;
   {
     double all = 0.0, dense = 0.0;                             // (slice_off[i + 1] still holds slice i's length here)
     for (uint64_t i = 0; i < n_slices; ++i) {
       const double len = double(slice_off[i + 1]);
       all += len * len;
-      if (slice_off[i + 1] >= dense_min) dense += len * len;
+      if (is_dense(slice_off[i + 1])) dense += len * len;
     }
     dense_share = all > 0.0 ? dense / all : 0.0;
   }
@@ -311,12 +310,10 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
     for (size_t i = 0; i < kHotCodes; ++i) hot_sq += double(top[i]) * double(top[i]);
     ws_gain = hot_sq / double(nnz) / double(n_win) * (double(nnz) / double(n_refs));
   }
-  const bool with_bitmaps = opt.wants_bitmaps(n_win, mean_hit_slice);
-  std::vector<uint32_t> bm_id(with_bitmaps ? n_slices : 0, kNoBitmap);
   uint32_t n_bitmaps = 0;
   for (uint64_t i = 0; i < n_slices; ++i) {
-    if (with_bitmaps && slice_off[i + 1] >= dense_min) bm_id[i] = n_bitmaps++;
-    const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
+    uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
+    if (len >= dense_min8) { len += kBitmapSlots; ++n_bitmaps; }
     n_slots += len;
     if (n_slots > 0xFFFF0000ull) { errno = EPROTO; return -1; }
     slice_off[i + 1] = uint32_t(n_slots);
@@ -331,23 +328,32 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   // in (bank, rank) order round-robin over the 16 instruction-halves, so one half sees each
   // bank -- and each counter word -- about once.
   std::vector<uint16_t> ent(n_slots + kEntPad, kPadRank);
-  std::vector<uint32_t> bitmaps(size_t(n_bitmaps) * kBitmapWords, 0u);
   parallel_codes([&](uint32_t t) {
     const uint32_t used = code_total[t];
     if (!used) return;
     const uint32_t* rk = rank.data() + bucket_base[t];
-    std::vector<uint32_t> fill(n_win, 0);
+    // where the postings of this code's slice of window w start (behind the bitmap of a dense slice, zeroed here)
+    std::vector<uint32_t> fill(n_win, 0), post0(n_win, 0);
+    std::vector<uint8_t> dense(n_win, 0);
+    for (uint32_t w = 0; w < n_win; ++w) {
+      const uint64_t i = uint64_t(w) * kNumCodes + t;
+      post0[w] = slice_off[i];
+      if (slice_off[i + 1] - slice_off[i] >= dense_min8) {                                // (a slice belongs to one worker: no race)
+        dense[w] = 1;
+        post0[w] += kBitmapSlots;
+        std::fill(ent.begin() + slice_off[i], ent.begin() + slice_off[i] + kBitmapSlots, uint16_t(0));
+      }
+    }
     for (uint32_t j = 0; j < used; ++j) {
       const uint32_t w = rk[j] / kWindowRanks, r = rk[j] % kWindowRanks;
-      ent[slice_off[uint64_t(w) * kNumCodes + t] + fill[w]++] = uint16_t(r);
-      const uint32_t id = with_bitmaps ? bm_id[uint64_t(w) * kNumCodes + t] : kNoBitmap;   // (a slice belongs to one worker: no race)
-      if (id != kNoBitmap) bitmaps[size_t(id) * kBitmapWords + (r >> 5)] |= 1u << (r & 31);
+      ent[post0[w] + fill[w]++] = uint16_t(r);
+      if (dense[w]) ent[post0[w] - kBitmapSlots + (r >> 4)] |= uint16_t(1u << (r & 15));   // little-endian: bit r of the u32 words
     }
     std::vector<uint16_t> tmp;
     for (uint32_t w = 0; w < n_win; ++w) {
       const uint32_t m = fill[w];
       if (m < 16) continue;                                   // a lane or two: nothing to arrange
-      uint16_t* sl = ent.data() + slice_off[uint64_t(w) * kNumCodes + t];
+      uint16_t* sl = ent.data() + post0[w];
       const uint32_t padded = (m + 7u) & ~7u;
       for (uint32_t u0 = 0; u0 < padded; u0 += 512) {         // one wave-load at a time
         const uint32_t len = std::min(512u, padded - u0), G = len / 8;
@@ -410,6 +416,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   ix.device = dev; ix.n_refs = n_refs; ix.n_windows = n_win; ix.n_entries = nnz; ix.n_slots = n_slots;
   ix.built_from = host.generation();
   ix.n_bitmaps = n_bitmaps;
+  ix.dense_min8 = dense_min8;
   ix.mean_hit_slice = mean_hit_slice;
   ix.dense_share = dense_share;
   ix.ws_gain = ws_gain;
@@ -426,8 +433,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   if (up(&ix.d_ref_of_rank, ref_of_rank, 1) || up(&ix.d_weight_of_rank, weight_of_rank, 1) ||
       up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
       up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1) ||
-      up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1) ||
-      (with_bitmaps && (up(&ix.d_bm_id, bm_id, 1) || up(&ix.d_bitmaps, bitmaps, 1)))) {
+      up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1)) {
     const int e = errno;
     device_index_free(&ix);
     errno = e;
@@ -436,6 +442,43 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   stage("upload");
   ix.h_sorted_ref.swap(sorted_ref);
   ix.h_rank_of_pos.swap(rank_of_pos);
+  device_index_free(out);
+  *out = std::move(ix);
+  return 0;
+}
+
+int device_index_clone(const DeviceIndex& src, int dst_device, DeviceIndex* out) {
+  int prev = 0;
+  BLURRILY_HIP_TRY(hipGetDevice(&prev));
+  DeviceIndex ix;
+  ix.device = dst_device; ix.n_refs = src.n_refs; ix.n_windows = src.n_windows; ix.nib_windows = src.nib_windows;
+  ix.n_entries = src.n_entries; ix.n_slots = src.n_slots; ix.built_from = src.built_from;
+  ix.n_bitmaps = src.n_bitmaps; ix.dense_min8 = src.dense_min8;
+  ix.mean_hit_slice = src.mean_hit_slice; ix.dense_share = src.dense_share; ix.ws_gain = src.ws_gain;
+  bool failed = hipSetDevice(dst_device) != hipSuccess;
+  auto copy = [&](auto** dptr, const auto* from, size_t elems) {
+    using T = typename std::remove_const<typename std::remove_pointer<decltype(from)>::type>::type;
+    const size_t bytes = std::max<size_t>(elems, 1) * sizeof(T);
+    if (failed || hipMalloc(reinterpret_cast<void**>(dptr), bytes) != hipSuccess) { failed = true; return; }
+    ix.device_bytes += bytes;
+    if (elems && hipMemcpyPeer(*dptr, dst_device, from, src.device, elems * sizeof(T)) != hipSuccess) failed = true;
+  };
+  copy(&ix.d_ref_of_rank, src.d_ref_of_rank, src.n_refs);
+  copy(&ix.d_weight_of_rank, src.d_weight_of_rank, src.n_refs);
+  copy(&ix.d_slice_off, src.d_slice_off, size_t(src.n_windows) * kNumCodes + 1);
+  copy(&ix.d_ent, src.d_ent, size_t(src.n_slots) + kEntPad);
+  copy(&ix.d_code_total, src.d_code_total, kNumCodes);
+  copy(&ix.d_win_max_tri, src.d_win_max_tri, src.n_windows);
+  copy(&ix.d_start_win, src.d_start_win, 256);
+  copy(&ix.d_tomb, src.d_tomb, (size_t(src.n_refs) + 31) / 32 + 1);
+  if (failed) {
+    std::fprintf(stderr, "blurrily_hip: cloning the device image onto device %d failed\n", dst_device);
+    device_index_free(&ix);
+    (void)hipSetDevice(prev);
+    errno = ENOMEM;
+    return -1;
+  }
+  (void)hipSetDevice(prev);
   device_index_free(out);
   *out = std::move(ix);
   return 0;

@@ -44,9 +44,14 @@ struct FindArgs {
   const uint32_t* win_max_tri; // [n_windows] match-count bound per window
   uint32_t        nib_windows; // windows [0, nib_windows): no reference with more than 15 trigrams (4-bit counters suffice)
   const uint32_t* tomb;        // bit r set: rank r was deleted after the image was built (nullptr: none)
-  // window-major sweep (wsweep_kernel): bitmaps of the dense slices, and how the work is split
-  const uint32_t* bm_id;       // [n_windows * kNumCodes] bitmap number of a dense slice, else kNoBitmap
-  const uint32_t* bitmaps;     // [n_bitmaps * kBitmapWords]
+  // dense slices start with their bitmap (device_index.h): a slice spanning at least this many entries is dense
+  uint32_t        dense_min8;
+  // needle-major sweep (sweep_coop): with a threshold, the largest slices of at least nm_dense postings are left out
+  // of a step's count -- at most need - nm_cmin of them per window -- and settled per candidate through their bitmaps
+  // (nm_cmin 0: nothing is ever left out)
+  uint32_t        nm_dense;
+  uint32_t        nm_cmin;
+  // window-major sweep (wsweep_kernel)
   uint32_t        own_only;    // find_kernel: sweep only the window pair of the needle's own length class and leave
                                // the best keys (not rows) in `results` as the needle's state for wsweep_kernel
   uint32_t        cmin;        // wsweep: a skipped slice must leave at least this many matches to count (>= 1)
@@ -99,6 +104,7 @@ enum : uint32_t {
   kPathWsPoolOv     = 1u << 18,   //   ... the candidate pool overflowed
   kPathWsWide       = 1u << 19,   //   ... byte counters over the two halves of the window
   kPathWsTableWalk  = 1u << 20,   //   ... more than 64 units: the waves walked the published slice table
+  kPathNmLeftOut    = 1u << 21,   // needle-major sweep: a candidate settled through the bitmaps of left-out slices
 };
 
 // slots of FindArgs::stats

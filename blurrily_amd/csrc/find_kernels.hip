@@ -41,6 +41,7 @@
 #include <atomic>
 #include <cerrno>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -347,6 +348,8 @@ template <typename CT> struct ScanTraits {
   static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
     return wbase + (sizeof(CT) == 1 ? idx ^ 3u : idx);
   }
+  // which window of the step a counter belongs to (one window per step here)
+  static __device__ __forceinline__ uint32_t parity_of(uint32_t) { return 0u; }
   // a short window does not reach the vector holding the padding slot: clear it here
   static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
     if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
@@ -379,6 +382,7 @@ template <> struct ScanTraits<Nib> {
   static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
     return wbase + (idx & 1u) * kWindowRanks + ((idx >> 1) ^ 3u);
   }
+  static __device__ __forceinline__ uint32_t parity_of(uint32_t idx) { return idx & 1u; }
   static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
     if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
   }
@@ -389,11 +393,13 @@ template <> struct ScanTraits<Nib> {
 struct Control {            // workgroup-shared scalars
   unsigned long long thr;   // admission threshold: the keep-th best key seen (kKeyInf: none yet)
   unsigned long long floor; // keys at or before this one were delivered by earlier passes
-  uint32_t pool_n;
+  uint32_t pool_n;          // (pool_n, overflow, pend_n[2]: ONE 16-byte read, the hot loop's glance behind a scan)
   uint32_t overflow;
+  uint32_t pend_n[2];       // sweep_coop: candidates of a step waiting to be settled through bitmaps, by ring slot
   uint32_t q;
   uint32_t tally;           // scratch of cold_start_need
 };
+static_assert(offsetof(Control, pool_n) % 16 == 0, "the glance reads pool_n .. pend_n[1] as one vector");
 
 // One posting = one relaxed LDS atomic (result unused -> ds_add_u32) on the word holding the
 // rank's counter.  This is the generic form (16-bit counters); byte and 4-bit counters take the
@@ -518,6 +524,12 @@ __device__ __forceinline__ void stat_unit(unsigned long long* stats, const uint4
   if (m && (threadIdx.x & 63) == 0) atomicAdd(&stats[kStatPostingEntries], 8ull * __popcll(m));
 }
 
+// Where the postings of the slice [a, b) of the slice table start: a DENSE slice (a span of at least dense_min8
+// entries) begins with its bitmap over the window's ranks, kBitmapSlots entries (device_index.h).
+__device__ __forceinline__ uint32_t postings_start(uint32_t a, uint32_t b, uint32_t dense_min8) {
+  return b - a >= dense_min8 ? a + kBitmapSlots : a;
+}
+
 __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uint32_t b) {
   uint4 v = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   if (c < b) v = *reinterpret_cast<const uint4*>(ent + c);
@@ -602,12 +614,18 @@ __device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint3
 // `need`: counters below it cannot enter the pool (the caller's bound: from the threshold, or the cold start's);
 // `cap`: no counter of this sweep exceeds it.  The threshold itself (*thr_p, in LDS: it does not change while a
 // scan runs) is read only where a counter is harvested.
+// `ls`: slices LEFT OUT of this step's count (sweep_coop: L of the even window in bits 3:0, of the odd one in bits
+// 7:4; 0: none) -- a harvested counter of such a window holds the matches among the counted slices only, `need` was
+// lowered by the publishing wave accordingly, and the candidate does NOT enter the pool here: if its best case
+// (every left-out slice a match) beats the threshold it goes to the step's PENDING list as in-window rank | parity
+// << 16 | counted matches << 20, and sweep_coop settles it through the left-out slices' bitmaps a step later.
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const uint32_t need, const uint32_t cap,
                                           const unsigned long long* thr_p, const unsigned long long* floor,
                                           const uint32_t* tomb, unsigned long long* pool, const uint32_t pool_cap,
                                           uint32_t* pool_n, uint32_t* overflow, uint32_t wbase, uint32_t wlen,
-                                          uint32_t* path_flag = nullptr) {
+                                          uint32_t* path_flag = nullptr, const uint32_t ls = 0, uint32_t* pend = nullptr,
+                                          uint32_t* pend_n = nullptr, const uint32_t pend_cap = 0) {
   using P = Packing<CT>;
   using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x;
@@ -630,7 +648,24 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
           m &= m - 1;
           const uint32_t pos = bit / P::kBits;
           const uint32_t cnt = (wv >> (pos * P::kBits)) & P::kMask;
-          const uint32_t rank = S::rank_of(wbase, (i * 4 + j) * P::kPerWord + pos);
+          const uint32_t idx = (i * 4 + j) * P::kPerWord + pos;
+          const uint32_t rank = S::rank_of(wbase, idx);
+          if (ls) {
+            const uint32_t h = S::parity_of(idx);
+            const uint32_t L = (ls >> (4u * h)) & 15u;
+            if (L) {                                   // slices of this window were left out of the count
+              const unsigned long long best = (static_cast<unsigned long long>(nd.T - min(nd.T, cnt + L)) << 32) | rank;
+              bool maybe = best <= thr;
+              if (tomb) maybe = maybe && ((tomb[rank >> 5] >> (rank & 31)) & 1u) == 0;
+              if (maybe) {
+                const uint32_t at = atomicAdd(pend_n, 1u);
+                if (at < pend_cap) pend[at] = (rank - wbase - h * kWindowRanks) | (h << 16) | (cnt << 20);
+                else *overflow = 1;                    // (the step is swept again, every slice counted)
+                if (path_flag) atomicOr(path_flag, kPathNmLeftOut);
+              }
+              continue;
+            }
+          }
           const unsigned long long key = (static_cast<unsigned long long>(nd.T - cnt) << 32) | rank;
           bool pass = key <= thr;
           if (nd.has_floor) pass = pass && key > *floor;
@@ -809,7 +844,8 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
         const uint32_t tc = min(kCodeChunk, nd.T - c0);
         if (tid < tc) {
           const uint32_t code = codes[c0 + tid];
-          s_a[tid] = soff[code]; s_b[tid] = soff[code + 1];
+          const uint32_t sb_ = soff[code + 1];
+          s_a[tid] = postings_start(soff[code], sb_, A.dense_min8); s_b[tid] = sb_;
         }
         __syncthreads();
         touched |= count_window<CT, kNW>(A, cnt32, s_a, s_b, tc, wid, lane);
@@ -918,8 +954,8 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
     A0 = B0 = A1 = B1 = 0;                                                       \
     if ((w_) < nwin) {                                                           \
       const uint32_t* soff_ = A.slice_off + size_t(w_) * kNumCodes;              \
-      if (own0) { A0 = soff_[code0]; B0 = soff_[code0 + 1]; }                    \
-      if (own1) { A1 = soff_[code1]; B1 = soff_[code1 + 1]; }                    \
+      if (own0) { B0 = soff_[code0 + 1]; A0 = postings_start(soff_[code0], B0, A.dense_min8); } \
+      if (own1) { B1 = soff_[code1 + 1]; A1 = postings_start(soff_[code1], B1, A.dense_min8); } \
     }                                                                            \
   } while (0)
 
@@ -1018,7 +1054,8 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // itself (BLURRILY_COUNT_WALK).
 constexpr uint32_t kRingUnitsMax = 512;
 __host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) {
-  return pool_cap <= 512 ? kRingUnitsMax : pool_cap <= 1024 ? 384u : 256u;       // (multiples of the sixteen waves)
+  return pool_cap <= 512 ? kRingUnitsMax : 256u;       // (multiples of the sixteen waves; a 1 024-entry pool had 384
+                                                       //  units through round 3: the pending lists took the difference)
 }
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two
 // row broadcasts of gfx9): ten VALU instructions, against six dependent ds_bpermute round trips for __shfl_up.
@@ -1038,15 +1075,27 @@ struct UnitRing {
   // what a step starts with, ONE 8-byte read: .x the step the slot's units belong to (past the end: none left),
   // .y the number of units (kRingWalk: too many, walk the table) | the scan's admission bound << 16 (0: the slow
   // scan, which works it out itself -- cold start)
+  // .y = units (bits 15:0; kRingWalk: too many, walk the table) | the scan's admission bound << 16 (bits 23:16;
+  // 0: the slow scan, which works it out itself -- cold start) | slices left out of the even window's count << 24
+  // (bits 27:24) | of the odd window's << 28
   uint2    hdr[2];
   uint32_t visit[2];                                            // the visit index chosen most recently, by turns
   uint32_t pad_[2];
+  // per step (e & 3: a step's candidates are settled while the step after the next is being published) and window
+  // parity: where the postings of the slices LEFT OUT of the count start in `ent` (their bitmaps sit in front of them)
+  uint32_t hot[4][2][8];
   // behind it: desc[2][ring_units_for(pool_cap)], .x first entry of the unit, .y end of its slice
 };
 __device__ __forceinline__ uint2* ring_slot(UnitRing* ring, uint32_t slot, uint32_t ring_units) {
   return reinterpret_cast<uint2*>(ring + 1) + (slot ? ring_units : 0u);
 }
 constexpr uint32_t kRingWalk = 0xFFFFu;
+constexpr uint32_t kNmMaxLeftOut = 8;                           // slices left out of one window's count at most (UnitRing::hot)
+// candidates of one step waiting for their bitmap words, per ring slot: behind the descriptors in the dynamic LDS
+constexpr uint32_t kPendMax = 256;
+__device__ __forceinline__ uint32_t* pend_list(UnitRing* ring, uint32_t slot, uint32_t ring_units) {
+  return reinterpret_cast<uint32_t*>(reinterpret_cast<uint2*>(ring + 1) + 2 * ring_units) + slot * kPendMax;
+}
 static_assert(kRingUnitsMax < kRingWalk, "a unit count is sixteen bits of the step header");
 
 // why sweep_coop's hot loop was left
@@ -1106,11 +1155,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (STATS(A) && w_ < w1) st_tab += 2u * tc * (kNib && w_ + 1 < w1 ? 2u : 1u); \
     if (w_ < w1 && own) {                                                        \
       const uint32_t idx_ = w_ * kNumCodes + code;                               \
-      A0 = A.slice_off[idx_]; B0 = A.slice_off[idx_ + 1];                        \
+      B0 = A.slice_off[idx_ + 1]; A0 = postings_start(A.slice_off[idx_], B0, A.dense_min8); \
     }                                                                            \
     if (kNib && w_ + 1 < w1 && own) {                                            \
       const uint32_t idx_ = (w_ + 1) * kNumCodes + code;                         \
-      A1 = A.slice_off[idx_]; B1 = A.slice_off[idx_ + 1];                        \
+      B1 = A.slice_off[idx_ + 1]; A1 = postings_start(A.slice_off[idx_], B1, A.dense_min8); \
     }                                                                            \
   } while (0)
   // The header of step step_ in ring slot s_, by lane 0 of the publishing wave: the step, its unit count and the
@@ -1119,12 +1168,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // the step in between), so the published bound is at most too low: the scan then looks at a few counters more,
   // and every counter it looks at is tested against the threshold of the moment before it enters the pool.
   // 0 = no threshold yet and a cold start due: the slow scan.
-#define BLURRILY_PUBLISH_HDR(s_, step_, nu_)                                     \
+#define BLURRILY_PUBLISH_HDR(s_, step_, nu_, need_, ls_)                         \
   do {                                                                           \
-    const unsigned long long thr_ = ctl->thr;                                    \
-    uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFFFu); \
-    if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
-    if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | (need_ << 16));   \
+    if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | ((need_) << 16) | ((ls_) << 24)); \
   } while (0)
   // (A window in which fewer of the needle's trigrams occur AT ALL than a candidate needs, left out by the publishing
   // wave -- two ballots over the table it holds -- measured in round 3: 255.5 vs 252.9 ms, 1 % slower: at Geonames
@@ -1134,13 +1180,47 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // wave by wave, so that ONE read -- lane j the wave's j-th unit -- hands a wave all its descriptors of a step.
 #define BLURRILY_UNIT_AT(k_) (((k_) & (kNW - 1)) * ring_rows + (k_) / kNW)
 #define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + min(lane, ring_rows - 1)])
-#define BLURRILY_PRODUCE(s_, step_, A0, B0, A1, B1)                              \
+  // LEFT OUT of the count (round 4; the MaxScore argument of wsweep_kernel, inside the needle-major step): once the
+  // needle has a threshold -- `need_` matches to enter its top `keep` in this step's windows -- the l_max_ = need_ -
+  // nm_cmin LARGEST slices of at least nm_dense postings of a window need not be counted.  A reference with need_
+  // matches has at least need_ - L of them among the counted slices, so the scan finds it with the bound lowered by
+  // L, and its exact count is settled from the left-out slices' bitmaps where it is harvested (scan_core).  Lane t
+  // ranks its slice among the window's dense ones by size (one readlane per dense slice); the chosen ones publish
+  // where their postings start (UnitRing::hot) and list no units.
+#define BLURRILY_LEAVE_OUT(hs_, h_, A_, B_, units_)                              \
   do {                                                                           \
-    const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
+    const uint32_t size_ = (B_) - (A_);                                          \
+    const bool dense_ = size_ >= A.nm_dense;                                     \
+    uint32_t bigger_ = 0;                                                        \
+    for (unsigned long long m_ = __ballot(dense_); m_; m_ &= m_ - 1) {           \
+      const uint32_t u_ = __builtin_ctzll(m_);                                   \
+      const uint32_t su_ = __builtin_amdgcn_readlane(size_, u_);                 \
+      bigger_ += (su_ > size_ || (su_ == size_ && u_ < lane)) ? 1u : 0u;         \
+    }                                                                            \
+    const bool skip_ = dense_ && bigger_ < l_max_;                               \
+    const unsigned long long sm_ = __ballot(skip_);                              \
+    if (skip_) {                                                                 \
+      ring->hot[hs_][h_][__popcll(sm_ & ((1ull << lane) - 1ull))] = (A_);        \
+      units_ = 0;                                                                \
+    }                                                                            \
+    ls_ |= uint32_t(__popcll(sm_)) << (4u * (h_));                               \
+  } while (0)
+#define BLURRILY_PRODUCE(s_, hs_, step_, A0, B0, A1, B1)                         \
+  do {                                                                           \
+    const unsigned long long thr_ = ctl->thr;                                    \
+    uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFu); \
+    uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
+    uint32_t ls_ = 0;                                                            \
+    const uint32_t l_max_ = (thr_ != kKeyInf && A.nm_cmin != 0 && need_ > A.nm_cmin) ? min(need_ - A.nm_cmin, kNmMaxLeftOut) : 0u; \
+    if (l_max_) {                                                                \
+      BLURRILY_LEAVE_OUT(hs_, 0u, A0, B0, units0_);                              \
+      if (kNib) BLURRILY_LEAVE_OUT(hs_, 1u, A1, B1, units1_);                    \
+    }                                                                            \
+    if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
     const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
-    if (total_ > ring_units) {                                                   \
-      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk);                                \
+    if (total_ > ring_units) {                 /* every wave walks the table: ALL slices, nothing left out */ \
+      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk, need_, 0u);                     \
     } else {                                                                     \
       uint2* const slot_ = ring_slot(ring, s_, ring_units);                      \
       uint32_t at_ = incl_ - units0_ - units1_;                                  \
@@ -1148,7 +1228,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
         slot_[BLURRILY_UNIT_AT(at_)] = make_uint2(A0 + j_ * 512, B0);            \
       for (uint32_t j_ = 0; j_ < units1_; ++j_, ++at_)                           \
         slot_[BLURRILY_UNIT_AT(at_)] = make_uint2((A1 + j_ * 512) | 1u, B1);     \
-      BLURRILY_PUBLISH_HDR(s_, step_, total_);                                   \
+      /* the scan's bound, lowered by the most slices either window leaves out (a harvested counter is settled  \
+         exactly, so a bound that is too low for the other window costs a look, nothing else) */ \
+      const uint32_t lmost_ = max(ls_ & 15u, ls_ >> 4);                          \
+      BLURRILY_PUBLISH_HDR(s_, step_, total_, need_ - min(need_, lmost_), ls_);  \
     }                                                                            \
   } while (0)
   // The units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
@@ -1225,6 +1308,67 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
                               { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); \
                                 if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
   } while (0)
+  // ---- settling a step's PENDING candidates (slices were left out of its count) a step later ---------------------
+  // The scan of step e leaves them in pend_list(e & 1): in-window rank | parity << 16 | counted matches << 20.  Behind
+  // the scan barrier thread j takes the pair (candidate j >> sh, left-out slice j & (2^sh - 1)) and REQUESTS the word of
+  // that slice's bitmap holding the candidate's bit (PROBE_ISSUE); the word travels under step e + 1's count; in
+  // front of that step's count barrier the thread adds its bit to the candidate's entry (PROBE_SETTLE: one LDS
+  // atomic), behind the barrier thread c reads entry c -- now the candidate's exact match count -- and admits it to the
+  // pool, or not, like any harvested counter (PROBE_ADMIT).  No barrier of its own, no load latency on the step's
+  // critical path; two VGPRs (word, bit | candidate) live across the count.  The pairs go to the wave that is
+  // farthest from a turn (rt_: the thread's number counted from that wave's first lane).
+#define BLURRILY_PROBE_ISSUE(slot_, hs_, np_, ls_, rt_)                          \
+  do {                                                                           \
+    pmeta = 0;                                                                   \
+    const uint32_t lm_ = max((ls_) & 15u, (ls_) >> 4);                           \
+    const uint32_t sh_ = lm_ > 4u ? 3u : lm_ > 2u ? 2u : lm_ > 1u ? 1u : 0u;     \
+    if (((rt_) & ~63u) < ((np_) << sh_)) {               /* (wave-uniform) */    \
+      const uint32_t c_ = (rt_) >> sh_, i_ = (rt_) & ((1u << sh_) - 1u);         \
+      if (c_ < (np_)) {                                                          \
+        const uint32_t e_ = pend_list(ring, slot_, ring_units)[c_];              \
+        const uint32_t h_ = (e_ >> 16) & 1u;                                     \
+        if (i_ < (((ls_) >> (4u * h_)) & 15u)) {                                 \
+          const uint32_t base_ = ring->hot[hs_][h_][i_];                         \
+          pv = reinterpret_cast<const uint32_t*>(A.ent + (base_ - kBitmapSlots))[(e_ & 0xFFFFu) >> 5]; \
+          pmeta = 0x80000000u | (c_ << 5) | (e_ & 31u);                          \
+        }                                                                        \
+      }                                                                          \
+      if (STATS(A)) st_probe += __popcll(__ballot(pmeta != 0));                  \
+    }                                                                            \
+  } while (0)
+#define BLURRILY_PROBE_SETTLE(slot_)                                             \
+  do {                                                                           \
+    if (pmeta != 0 && ((pv >> (pmeta & 31u)) & 1u) != 0)                         \
+      __hip_atomic_fetch_add(&pend_list(ring, slot_, ring_units)[(pmeta >> 5) & 0xFFFFu], 1u << 20, __ATOMIC_RELAXED, \
+                             __HIP_MEMORY_SCOPE_WORKGROUP);                      \
+    pmeta = 0;                                                                   \
+  } while (0)
+#define BLURRILY_PROBE_ADMIT(slot_, np_, pstep_, rt_)                            \
+  do {                                                                           \
+    if (((rt_) & ~63u) < (np_)) {                        /* (wave-uniform) */    \
+      if ((rt_) < (np_)) {                                                       \
+        const uint32_t e_ = pend_list(ring, slot_, ring_units)[rt_];             \
+        const uint32_t rank_ = (pstep_) * kWPS * kWindowRanks + ((e_ >> 16) & 1u) * kWindowRanks + (e_ & 0xFFFFu); \
+        const unsigned long long key_ = (static_cast<unsigned long long>(tc - min(tc, e_ >> 20)) << 32) | rank_; \
+        bool pass_ = key_ <= ctl->thr;                                           \
+        if (nd.has_floor) pass_ = pass_ && key_ > ctl->floor;                    \
+        if (pass_) {                                     /* (tombstones were looked at where it was harvested) */ \
+          const uint32_t at_ = atomicAdd(&ctl->pool_n, 1u);                      \
+          if (at_ < A.pool_cap) pool[at_] = key_; else ctl->overflow = 1;        \
+        }                                                                        \
+      }                                                                          \
+      if ((rt_) == 0) ctl->pend_n[slot_] = 0;                                    \
+    }                                                                            \
+  } while (0)
+  // the same at once, for the rare paths: nothing stays in flight across them
+#define BLURRILY_PROBE_DRAIN(slot_, hs_, np_, ls_, pstep_)                       \
+  do {                                                                           \
+    BLURRILY_PROBE_ISSUE(slot_, hs_, np_, ls_, tid);                             \
+    BLURRILY_PROBE_SETTLE(slot_);                                                \
+    __syncthreads();                                                             \
+    BLURRILY_PROBE_ADMIT(slot_, np_, pstep_, tid);                               \
+    __syncthreads();                                                             \
+  } while (0)
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
   // The two turns a step has behind its units.  The wave whose turn it is publishes the next visited step (its
   // table arrived a step ago); the wave after it chooses the step after the next (the threshold only changes
@@ -1234,7 +1378,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (wid == BLURRILY_PRODUCER((e_) + 1)) {                                    \
       __builtin_amdgcn_s_setprio(3);                /* the wave the count barrier waits for goes first */ \
       if (my_i < n_visit) {                                                      \
-        BLURRILY_PRODUCE((s_) ^ 1u, BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);   \
+        BLURRILY_PRODUCE((s_) ^ 1u, ((e_) + 1u) & 3u, BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1); \
       } else if (lane == 0) {                                                    \
         ring->hdr[(s_) ^ 1u] = make_uint2(v1, 0u);                               \
       }                                                                          \
@@ -1255,7 +1399,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t lane8 = lane * 8, lane16 = lane * 16;
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
-  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0;    // request counters (FindArgs::stats), wave-uniform
+  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0, st_probe = 0;   // request counters (FindArgs::stats), wave-uniform
+  uint32_t pv = 0, pmeta = 0;                                   // a bitmap word on its way, and whose bit it holds (PROBE_*)
+  uint32_t np_prev = 0, p_prev = 0;                             // the step before: its pending candidates, its step
   // Which step comes next is decided by ONE wave per step -- the one that then fetches that step's table --
   // and travels through LDS with the units (`hdr[slot]`; the visit index chosen last in `visit[]`).  The other
   // fifteen waves read one header per step instead of each running the window-bound loop, the 64-bit threshold
@@ -1264,7 +1410,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
   if (wid == BLURRILY_PRODUCER(0u)) {
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
-    BLURRILY_PRODUCE(0u, BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
+    BLURRILY_PRODUCE(0u, 0u, BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
   }
   if (wid == BLURRILY_PRODUCER(1u)) {
     BLURRILY_NEXT_VISIT(1u, my_i);
@@ -1289,11 +1435,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // need is not held in registers, nor worked out, step after step.
   uint32_t e = 0;
   for (;;) {
-    uint32_t left, s, p, n_units;
+    uint32_t left, s, p, n_units, hy_, np_cur = 0;
     for (;; ++e) {
       s = e & 1;
       p = __builtin_amdgcn_readfirstlane(h_next.x);
-      const uint32_t hy_ = __builtin_amdgcn_readfirstlane(h_next.y);
+      hy_ = __builtin_amdgcn_readfirstlane(h_next.y);
       n_units = hy_ & 0xFFFFu;
       if (p >= v1) { left = kLeftDone; break; }                 // no step left
       ++st_steps;
@@ -1305,6 +1451,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       BLURRILY_COUNT_UNITS(s, n_units, true);
       PHASE_MARK(2);                                            // units counted
       BLURRILY_TAKE_TURNS(e, s);
+      // (the thread's number counted from the first lane of the wave farthest from a turn)
+      const uint32_t rt = (tid - 64u * ((e + 9u) & (kNW - 1))) & uint32_t(NT - 1);
+      if (np_prev) BLURRILY_PROBE_SETTLE(s ^ 1u);               // the step before's candidates: the bits have arrived
       __syncthreads();                                          // counts and next descriptors visible
       PHASE_MARK(3);                                            // barrier after count
       // The next step's header and this wave's units of it were published before that barrier: requested now,
@@ -1312,13 +1461,21 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // other workgroup's atomics), between the scan barrier and the first load of the next step.
       h_next = ring->hdr[s ^ 1u];
       d_mine = BLURRILY_MY_UNITS(s ^ 1u);
+      if (np_prev) { BLURRILY_PROBE_ADMIT(s ^ 1u, np_prev, p_prev, rt); np_prev = 0; }
       if (n_units == 0) continue;                               // nothing of the needle in this step's windows
-      const uint32_t need = hy_ >> 16;
+      const uint32_t need = (hy_ >> 16) & 0xFFu;
       if (need == 0) { left = kLeftSlowScan; break; }
       const uint32_t wbase = p * kWPS * kWindowRanks;
       const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-      scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n,
-                        &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
+      const uint32_t ls = hy_ >> 24;
+      {
+        // (a pair per thread: the pending list holds what the threads can settle)
+        const uint32_t lm = max(ls & 15u, ls >> 4);
+        const uint32_t pend_cap = min(kPendMax, uint32_t(NT) >> (lm > 4u ? 3u : lm > 2u ? 2u : lm > 1u ? 1u : 0u));
+        scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n,
+                          &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr,
+                          ls, pend_list(ring, s, ring_units), &ctl->pend_n[s], pend_cap);
+      }
       BLURRILY_PRELOAD();
       PHASE_MARK(5);                                            // scan
       __syncthreads();                                          // counters are zero again
@@ -1326,9 +1483,22 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // (Looking at the pool a count phase later -- the read requested here, used behind the next count barrier, a
       // compaction then running with the next step counted and not yet scanned -- was built and measured in round 3:
       // 2 % slower, 293.0 vs 287.2 ms per 500 k needles; the thresholds the headers carry are a step staler.)
-      const uint2 c_ = *reinterpret_cast<const uint2*>(&ctl->pool_n);          // pool_n, overflow
+      const uint4 c_ = *reinterpret_cast<const uint4*>(&ctl->pool_n);          // pool_n, overflow, pend_n[0], pend_n[1]
       const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x), ov_ = __builtin_amdgcn_readfirstlane(c_.y);
+      np_cur = __builtin_amdgcn_readfirstlane(s ? c_.w : c_.z);
       if (ov_ != 0 || pn_ > sel_at || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
+      if (np_cur) {                                             // this step's candidates: their bitmap words requested
+        BLURRILY_PROBE_ISSUE(s, e & 3u, np_cur, ls, rt);
+        np_prev = np_cur; p_prev = p;
+      }
+    }
+    // candidates of the step before whose words are under way (the loop was left in front of a count): settled now
+    if (np_prev) {
+      BLURRILY_PROBE_SETTLE((e & 1u) ^ 1u);
+      __syncthreads();
+      BLURRILY_PROBE_ADMIT((e & 1u) ^ 1u, np_prev, p_prev, tid);
+      __syncthreads();
+      np_prev = 0;
     }
     if (left == kLeftDone) break;
     // ---- the rare paths of step p ----------------------------------------------------------------
@@ -1344,6 +1514,18 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     }
     // kLeftSelect: the step is scanned, select_after_scan finds the pool as the hot loop saw it; else: scan first
     bool scanned = left == kLeftSelect;
+    if (scanned && np_cur) {
+      // the step's own pending candidates: settled at once -- unless the pool (or their list) overflowed: the step is
+      // then swept again with every slice counted, and they would come twice
+      if (ctl->overflow) {
+        __syncthreads();                                        // (everybody has read the flag)
+        if (tid == 0) ctl->pend_n[s] = 0;
+        __syncthreads();
+      } else {
+        BLURRILY_PROBE_DRAIN(s, e & 3u, min(np_cur, kPendMax), hy_ >> 24, p);
+      }
+      np_cur = 0;
+    }
     for (;;) {
       if (!scanned) {
         scan_window<CT, NT>(A, nd, cnt128, pool, ctl, wbase, wlen);
@@ -1351,8 +1533,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       }
       scanned = false;
       if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
-      ++st_redo;                                                // pool overflow: sweep step p again
-      if (n_units == kRingWalk) BLURRILY_COUNT_WALK(p);
+      ++st_redo;                                                // pool overflow: sweep step p again -- every slice of it
+      if (n_units == kRingWalk || (hy_ >> 24) != 0) BLURRILY_COUNT_WALK(p);   // (the ring lists no units of left-out slices)
       else BLURRILY_COUNT_UNITS(s, n_units, false);
       __syncthreads();
     }
@@ -1365,6 +1547,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   if (STATS(A) && lane == 0) {
     atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
     atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
+    atomicAdd(&STATS(A)[kStatProbes], static_cast<unsigned long long>(st_probe));
     if (wid == 0) {
       atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
       atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
@@ -1375,10 +1558,15 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   __syncthreads();                                              // ring and ctl quiet before the needle ends
 #undef BLURRILY_TAKE_TURNS
 #undef BLURRILY_PRODUCER
+#undef BLURRILY_PROBE_DRAIN
+#undef BLURRILY_PROBE_ADMIT
+#undef BLURRILY_PROBE_SETTLE
+#undef BLURRILY_PROBE_ISSUE
 #undef BLURRILY_COUNT_WALK
 #undef BLURRILY_COUNT_UNITS
 #undef BLURRILY_PRELOAD
 #undef BLURRILY_PRODUCE
+#undef BLURRILY_LEAVE_OUT
 #undef BLURRILY_MY_UNITS
 #undef BLURRILY_UNIT_AT
 #undef BLURRILY_PUBLISH_HDR
@@ -1476,6 +1664,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
     if (tid == 0) {
       ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf;
+      ctl->pend_n[0] = 0; ctl->pend_n[1] = 0;
       if (nd.has_floor) ctl->floor = A.floor[q];
     }
     __syncthreads();
@@ -2042,7 +2231,6 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
   const uint32_t wmt = A.win_max_tri[w];
   const uint32_t keep = A.keep;
   const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
-  const uint32_t* bmid = A.bm_id + size_t(w) * kNumCodes;
 
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   // request counters (FindArgs::stats), per wave
@@ -2095,7 +2283,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
   do {                                                                                    \
     nx_ta = nx_tb = 0; nx_bm = kNoBitmap;                                                 \
     if ((ti_) < n_tasks && lane < (s_task_meta[ti_] & 0xFFu)) {                           \
-      nx_ta = soff[nx_code]; nx_tb = soff[nx_code + 1]; nx_bm = bmid[nx_code];            \
+      const uint32_t raw_ = soff[nx_code];                                                \
+      nx_tb = soff[nx_code + 1]; nx_ta = postings_start(raw_, nx_tb, A.dense_min8);        \
+      nx_bm = nx_ta != raw_ ? nx_ta : kNoBitmap;       /* a dense slice: its bitmap sits in front of its postings */ \
     }                                                                                     \
   } while (0)
     // What a task's owner publishes for one pass over the window: which dense slices are left out (the L largest,
@@ -2155,7 +2345,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
       const bool own = lane < my_T;
       const uint32_t ta = nx_ta, tb0 = nx_tb, bm = nx_bm;     // (waits for the prefetched table)
       WS_FETCH_TABLE(g + kWsNW + wid);                        // next group: its codes arrived a group ago
-      if (STATS(A) && my_ti < n_tasks) { st_tab += 3 * my_T; ++st_tasks; }
+      if (STATS(A) && my_ti < n_tasks) { st_tab += 2 * my_T; ++st_tasks; }
       // Every wave publishes the first pass of its own task now, the four of them side by side -- from what the
       // filter learnt of the needle (its threshold's bound, whether it has one) -- instead of one after the other
       // with the other three waves waiting at a barrier (a fifth of a task's time, profiles/r03: "skipsel").  One
@@ -2330,7 +2520,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
                   x0[i] = x1[i] = 0;
                   if (i0 + i < L) {                                        // (uniform)
                     const uint32_t id = __builtin_amdgcn_readfirstlane(s_hot[j][i0 + i]);
-                    const uint32_t* bmw = A.bitmaps + size_t(id) * kBitmapWords;
+                    const uint32_t* bmw = reinterpret_cast<const uint32_t*>(A.ent + (id - kBitmapSlots));
                     if (has0) x0[i] = bmw[r0 >> 5];
                     if (has1) x1[i] = bmw[r1 >> 5];
                   }
@@ -2437,7 +2627,8 @@ __global__ void finalize_rows_kernel(const FindArgs A, const uint32_t n) {
 // dynamic LDS of find_kernel (the counters are static)
 size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
   static_assert(sizeof(Control) <= 64, "the unit ring sits 64 bytes behind the control block");
-  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 2 * size_t(ring_units_for(pool_cap)) * 8 + 16;
+  return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 2 * size_t(ring_units_for(pool_cap)) * 8 +
+         2 * kPendMax * 4 + 16;
 }
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
   return size_t(kWindowSize) * counter_bytes + find_dynamic_lds_bytes(pool_cap);

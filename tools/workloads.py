@@ -91,6 +91,14 @@ BENCH_WORKLOADS = {
                      label="configs[1]: 235k-word haystack, 100k batched needles"),
     "skewed":   dict(kind="skewed", n=4_000_000, hay_seed=5, queries=100_000, limit=100,
                      label="configs[4]: adversarial hot-trigram haystack, limit=100"),
+    # round 4: past the Infinity Cache (four times configs[2]'s haystack: the image is >= 7 x the 256 MiB cache) ...
+    "geonames_x4":   dict(kind="geonames", n=4 * 8423769, vocab=500000, hay_seed=3, queries=100_000, limit=10,
+                          label="four times configs[2]'s haystack (33.7M strings), 100k batched needles"),
+    # ... and needles WITHOUT a close match: configs[2]'s haystack, needles cut from a haystack of another seed's
+    # vocabulary -- what the reference's own bench does with its fixed city names on any dataset (bin/bench:24-25,160-162)
+    "geonames_miss": dict(kind="geonames", n=8423769, vocab=500000, hay_seed=3, queries=100_000, limit=10,
+                          needles_from=dict(n=200_000, vocab=500000, seed=1003),
+                          label="configs[2]'s haystack, 100k needles from a foreign vocabulary (no close match)"),
 }
 
 
@@ -107,5 +115,11 @@ def bench_haystack(name, scale=1.0):
 
 def bench_needles(hay, hay_off, name, scale=1.0, rank=0, world=1):
     """This rank's shard of the step batch: world x n_q needles in contiguous shards, seeded per rank."""
-    n_q = max(100, int(BENCH_WORKLOADS[name]["queries"] * scale))
-    return queries(hay, hay_off, n_q, (3 if world == 1 else 4) * 1000 + rank)
+    spec = BENCH_WORKLOADS[name]
+    n_q = max(100, int(spec["queries"] * scale))
+    seed = (3 if world == 1 else 4) * 1000 + rank
+    if "needles_from" in spec:                      # needles of another vocabulary: no close match in `hay`
+        src = spec["needles_from"]
+        f_hay, f_off = geonames(max(1000, int(src["n"] * min(1.0, scale * 4))), src["vocab"], src["seed"])
+        return queries(f_hay, f_off, n_q, seed)
+    return queries(hay, hay_off, n_q, seed)
