@@ -253,7 +253,20 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     spec = W.BENCH_WORKLOADS[name]
     limit = spec["limit"]
     m, hay, hay_off, entries_resident = build_haystack(name, args.scale, getattr(args, 'static_choice', False))
-    qp, qo = W.bench_needles(hay, hay_off, name, args.scale, rank, world)
+    # --in-process: ONE process, the device image replicated behind the C ABI (option "devices"), the batch of all
+    # the ranks of the torch.distributed run -- the same needles, shard for shard -- handed over in one call
+    devices = args.gpus if getattr(args, "in_process", False) else 1
+    if devices > 1:
+        shards = [W.bench_needles(hay, hay_off, name, args.scale, r, devices) for r in range(devices)]
+        qp = np.concatenate([p_ for p_, _ in shards])
+        base, offs = 0, [np.zeros(1, dtype=np.uint64)]
+        for p_, o_ in shards:
+            offs.append(o_[1:] + np.uint64(base))
+            base += int(o_[-1])
+        qo = np.concatenate(offs)
+        m.set_option("devices", devices)
+    else:
+        qp, qo = W.bench_needles(hay, hay_off, name, args.scale, rank, world)
     n_q = len(qo) - 1
     sum_T = W.count_trigrams(qp, qo)
 
@@ -359,8 +372,10 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     out_bytes = 12 * sum_rows + 4 * n_q + 4 * n_q                              # rows + counts + nb_entries
     needle_bytes = int(qo[-1]) + 8 * (n_q + 1) + 2 * (int(qo[-1]) + n_q)       # needles, offsets, code scratch (w+r)
     req_bytes = (2 * st["posting_entries"] + 4 * st["table_words"] + 4 * st["probes"] + out_bytes + 2 * needle_bytes)
-    req_gbs = req_bytes / (k_ms * 1e-3) / 1e9
-    lds_lanes = st["posting_entries"] / (k_ms * 1e-3)
+    # (in-process over several devices: the counted launch ran the whole batch on ONE of them; kernel_ms is the slowest
+    # shard's search, so the per-device rates take a device's share of the bytes)
+    req_gbs = req_bytes / devices / (k_ms * 1e-3) / 1e9
+    lds_lanes = st["posting_entries"] / devices / (k_ms * 1e-3)
     # Beside it: memory-side bytes per step from the rocprofv3 --pmc passes of this workload (a SEPARATE run of
     # this command under the profiler, profiles/traffic_latest.json): the L2's fabric-side counters, i.e. HBM +
     # Infinity Cache.  Only as good as the build it was taken at: stamped, and stale when the sources changed.
@@ -433,13 +448,15 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             "metric": "find() queries/sec (batched), Geonames-scale haystack",
             "value": world * n_q * steps / elapsed,
             "unit": "queries/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "n_gpus": world * devices, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": spec["label"], "haystack_strings": int(len(hay_off) - 1),
-                       "haystack_entries": int(entries_resident), "needles_per_gpu": n_q, "limit": limit,
-                       "index_replicated": world > 1, "parallelism": f"query-shard x{world}",
+                       "haystack_entries": int(entries_resident), "needles_per_gpu": n_q // devices, "limit": limit,
+                       "index_replicated": world * devices > 1,
+                       "parallelism": (f"query-shard x{devices}, in-process: replicas behind the C ABI (option \"devices\"), "
+                                       f"rows sent into device 0's buffers by peer copies" if devices > 1 else f"query-shard x{world}"),
                        "scale": args.scale},
             "p50_query_us": p50_us,
             "host_buffer_queries_per_sec": host_rate,
@@ -539,6 +556,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--latency-probes", type=int, default=200)
+    ap.add_argument("--in-process", action="store_true",
+                    help="--gpus N in ONE process: the image replicated on N devices behind the C ABI (option \"devices\"), "
+                         "the N ranks' needles in one call; no torch.distributed")
     ap.add_argument("--inject-failure", default=None, metavar="WORKLOAD",
                     help="(tests) make that workload's cpu_baseline leg raise: the line must carry the error and the exit status be 1")
     ap.add_argument("--static-choice", action="store_true",
@@ -549,9 +569,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
+    if args.in_process and world != 1:
+        raise SystemExit("--in-process is one process: do not launch it under torch.distributed.run")
+    if args.gpus != world and not args.in_process:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1")
+            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N for --gpus N > 1 (or pass --in-process)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: blurrily_amd has no CPU fallback")
     # (BLURRILY_DIST_BACKEND=gloo: plumbing smoke test of the N > 1 path on a box with fewer GPUs than ranks --
@@ -577,7 +599,7 @@ def main():
     budget = 0.0 if args.no_cpu_baseline else args.cpu_budget
     out, ok = run_workload(main_name, args, args.steps, args.warmup, rank, local_rank, world, dist, budget,
                            args.latency_probes)
-    if world == 1 and args.workload is None and not args.no_extra:
+    if world == 1 and args.workload is None and not args.no_extra and not args.in_process:
         extra = {}
         for name in EXTRA_CONFIGS:
             try:

@@ -307,7 +307,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   }
 
   FindArgs a{};
-  a.slice_off = ix.d_slice_off; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
+  a.slice_se = ix.d_slice_se; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
   a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
   a.offsets = d_offsets; a.qcodes = static_cast<const uint16_t*>(m->ws_codes.p);
   a.q_ntri = q_ntri; a.q_nb = q_nb; a.q_start = q_start; a.win_max_tri = ix.d_win_max_tri; a.nib_windows = ix.nib_windows; a.results = d_results; a.counts = d_counts; a.limit = limit;

@@ -14,19 +14,19 @@
 //     16-bit in-window ranks of the references whose string contains t, sorted,
 //     each 512-entry unit (one wave-load) stored transposed so that one LDS
 //     atomic instruction of the kernel covers consecutive sorted ranks.
-//     slice_off[w * kNumCodes + t] is the start of that slice in `ent`
+//     slice_se[w * kNumCodes + t] = {where the slice's postings start in `ent`, where they end}
 //     (a CSR over (window, code)); one extra element closes the last slice.
 //     Every slice starts on a 16-byte boundary and is padded to a multiple of
 //     eight entries with the sentinel 0xFFFF (the one in-window rank no
 //     reference uses), so the kernel counts whole 16-byte groups without any
 //     range check; counter slot 0xFFFF is a scratch slot the scan ignores.
 //   * a DENSE slice -- at least dense_min8 entries, padding included -- additionally exists as a bitmap over the
-//     window's ranks, stored INLINE in `ent` in front of its postings: slice_off[] spans bitmap + postings, the
-//     first kBitmapSlots entries (8 KiB) are the bitmap (bit r set iff in-window rank r holds the code), the
-//     postings follow.  A kernel tells a dense slice by its span alone (span >= dense_min8: a slice that is not
-//     dense is shorter than that, a dense one at least kBitmapSlots longer), so there is no table of bitmap
-//     numbers to load, and every image carries the bitmaps of its dense slices (round 4; rounds 2-3 kept
-//     bm_id[] + bitmaps[] beside `ent`, only on images the window-major sweep could run on).  Both sweeps leave
+//     window's ranks, stored INLINE in `ent` in front of its postings: the kBitmapSlots entries (8 KiB) before
+//     slice_se[].x are the bitmap (bit r set iff in-window rank r holds the code).  A kernel tells a dense slice by
+//     its length alone (end - start >= dense_min8), so there is no table of bitmap numbers to load, a kernel that
+//     leaves nothing out never sees the bitmaps (one 8-byte load hands it a slice's bounds), and every image carries
+//     the bitmaps of its dense slices (round 4; rounds 2-3 kept bm_id[] + bitmaps[] beside `ent`, only on images the
+//     window-major sweep could run on).  Both sweeps leave
 //     dense slices out of the count where the threshold allows and ask the bitmap about the few ranks that matter
 //     (find_kernels.hip: sweep_coop, wsweep_kernel).
 //   * code_total[t] = used[t] of the reference's bucket t (storage.c:501), for
@@ -42,6 +42,8 @@
 // reference's 8 bytes.
 #pragma once
 #include <cstdint>
+
+#include <hip/hip_vector_types.h>
 #include <vector>
 
 #include "host_index.h"
@@ -76,7 +78,7 @@ struct DeviceIndex {
   uint64_t  built_from    = 0;        // HostIndex::generation() this was built from
   uint32_t* d_ref_of_rank    = nullptr;   // [n_refs]
   uint32_t* d_weight_of_rank = nullptr;   // [n_refs]
-  uint32_t* d_slice_off      = nullptr;   // [n_windows * kNumCodes + 1]
+  uint2*    d_slice_se       = nullptr;   // [n_windows * kNumCodes] {start, end} of every slice's postings in d_ent
   uint16_t* d_ent            = nullptr;   // [n_slots + kEntPad]
   uint32_t* d_code_total     = nullptr;   // [kNumCodes]
   uint32_t* d_win_max_tri    = nullptr;   // [n_windows] most postings any one reference of the window has

@@ -79,7 +79,7 @@ void device_index_free(DeviceIndex* ix) {
   if (!ix) return;
   if (ix->d_ref_of_rank)    (void)hipFree(ix->d_ref_of_rank);
   if (ix->d_weight_of_rank) (void)hipFree(ix->d_weight_of_rank);
-  if (ix->d_slice_off)      (void)hipFree(ix->d_slice_off);
+  if (ix->d_slice_se)       (void)hipFree(ix->d_slice_se);
   if (ix->d_ent)            (void)hipFree(ix->d_ent);
   if (ix->d_code_total)     (void)hipFree(ix->d_code_total);
   if (ix->d_win_max_tri)    (void)hipFree(ix->d_win_max_tri);
@@ -393,6 +393,13 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
     }
   });
   stage("scatter + deal units");
+  // what the kernels read: {start, end} of every slice's postings (a dense slice's bitmap sits in front of start)
+  std::vector<uint2> slice_se(n_slices);
+  for (uint64_t i = 0; i < n_slices; ++i) {
+    const uint32_t a = slice_off[i], b = slice_off[i + 1];
+    slice_se[i] = make_uint2(b - a >= dense_min8 ? a + kBitmapSlots : a, b);
+  }
+  std::vector<uint32_t>().swap(slice_off);
   // per-window bound and per-weight start window
   std::vector<uint32_t> win_max_tri(n_win, 0), start_win(256, n_win - 1);
   {
@@ -431,7 +438,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
     return 0;
   };
   if (up(&ix.d_ref_of_rank, ref_of_rank, 1) || up(&ix.d_weight_of_rank, weight_of_rank, 1) ||
-      up(&ix.d_slice_off, slice_off, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
+      up(&ix.d_slice_se, slice_se, 1) || up(&ix.d_ent, ent, 1) || up(&ix.d_code_total, code_total, 1) ||
       up(&ix.d_win_max_tri, win_max_tri, 1) || up(&ix.d_start_win, start_win, 1) ||
       up(&ix.d_tomb, std::vector<uint32_t>((size_t(n_refs) + 31) / 32 + 1, 0u), 1)) {
     const int e = errno;
@@ -465,7 +472,7 @@ int device_index_clone(const DeviceIndex& src, int dst_device, DeviceIndex* out)
   };
   copy(&ix.d_ref_of_rank, src.d_ref_of_rank, src.n_refs);
   copy(&ix.d_weight_of_rank, src.d_weight_of_rank, src.n_refs);
-  copy(&ix.d_slice_off, src.d_slice_off, size_t(src.n_windows) * kNumCodes + 1);
+  copy(&ix.d_slice_se, src.d_slice_se, size_t(src.n_windows) * kNumCodes);
   copy(&ix.d_ent, src.d_ent, size_t(src.n_slots) + kEntPad);
   copy(&ix.d_code_total, src.d_code_total, kNumCodes);
   copy(&ix.d_win_max_tri, src.d_win_max_tri, src.n_windows);

@@ -29,7 +29,7 @@ struct TokeniseArgs {
 
 struct FindArgs {
   // index
-  const uint32_t* slice_off;
+  const uint2*    slice_se;    // [n_windows * kNumCodes] {start, end} of a slice's postings in `ent`
   const uint16_t* ent;
   const uint32_t* ref_of_rank;
   const uint32_t* weight_of_rank;
@@ -111,7 +111,7 @@ enum : uint32_t {
 enum : uint32_t {
   kStatPostingEntries = 0,   // 16-bit postings loaded (x2 = bytes); each is also one LDS-atomic lane
   kStatSteps          = 1,   // sweep steps (count -> barrier -> scan -> barrier)
-  kStatTableWords     = 2,   // slice_off words loaded (x4 = bytes)
+  kStatTableWords     = 2,   // slice-table words loaded (x4 = bytes)
   kStatTasks          = 3,   // needles (or needle ranges) swept
   kStatCompactions    = 4,   // candidate-pool compactions
   kStatResweeps       = 5,   // windows swept again after a pool overflow

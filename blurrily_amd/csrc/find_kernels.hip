@@ -388,18 +388,23 @@ template <> struct ScanTraits<Nib> {
   }
 };
 
+// sweep_coop's pending lists (candidates of a step that left slices out of its count, waiting for their bitmap
+// words), one per ring slot, and the pool's tail that takes the ones that pass (compact_pool)
+constexpr uint32_t kPendMax = 128, kAdmMax = 128;
+
 // A candidate is one 64-bit key: (T - matches) in the high word, rank in the low word.  Ranks
 // follow (weight, reference), so ascending keys are the reference's result order.
 struct Control {            // workgroup-shared scalars
   unsigned long long thr;   // admission threshold: the keep-th best key seen (kKeyInf: none yet)
   unsigned long long floor; // keys at or before this one were delivered by earlier passes
-  uint32_t pool_n;          // (pool_n, overflow, pend_n[2]: ONE 16-byte read, the hot loop's glance behind a scan)
+  uint32_t pool_n;          // (pool_n, overflow, adm_n, q: ONE 16-byte read, the hot loop's glance behind a scan)
   uint32_t overflow;
-  uint32_t pend_n[2];       // sweep_coop: candidates of a step waiting to be settled through bitmaps, by ring slot
+  uint32_t adm_n;           // sweep_coop: keys in the pool's tail -- settled candidates, merged in by compact_pool
   uint32_t q;
+  uint32_t pend_n[2];       // sweep_coop: candidates of a step waiting to be settled through bitmaps, by ring slot
   uint32_t tally;           // scratch of cold_start_need
 };
-static_assert(offsetof(Control, pool_n) % 16 == 0, "the glance reads pool_n .. pend_n[1] as one vector");
+static_assert(offsetof(Control, pool_n) % 16 == 0, "the glance reads pool_n .. q as one vector");
 
 // One posting = one relaxed LDS atomic (result unused -> ds_add_u32) on the word holding the
 // rank's counter.  This is the generic form (16-bit counters); byte and 4-bit counters take the
@@ -524,12 +529,6 @@ __device__ __forceinline__ void stat_unit(unsigned long long* stats, const uint4
   if (m && (threadIdx.x & 63) == 0) atomicAdd(&stats[kStatPostingEntries], 8ull * __popcll(m));
 }
 
-// Where the postings of the slice [a, b) of the slice table start: a DENSE slice (a span of at least dense_min8
-// entries) begins with its bitmap over the window's ranks, kBitmapSlots entries (device_index.h).
-__device__ __forceinline__ uint32_t postings_start(uint32_t a, uint32_t b, uint32_t dense_min8) {
-  return b - a >= dense_min8 ? a + kBitmapSlots : a;
-}
-
 __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uint32_t b) {
   uint4 v = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
   if (c < b) v = *reinterpret_cast<const uint4*>(ent + c);
@@ -538,11 +537,24 @@ __device__ __forceinline__ uint4 load_group(const uint16_t* ent, uint32_t c, uin
 
 // Sort the candidate pool ascending, keep the best `keep`, and tighten the admission
 // threshold.  Called by all threads of the workgroup.
+// (`scan_cap`: the slots the scans fill -- all of them, or all but the last kAdmMax where sweep_coop leaves slices out)
 template <int NT>
-__device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t cap, uint32_t keep) {
+__device__ void compact_pool(unsigned long long* pool, Control* ctl, uint32_t cap, uint32_t keep, uint32_t scan_cap = 0) {
+  if (scan_cap == 0) scan_cap = cap;
   __builtin_amdgcn_s_setprio(kSerialPrio);            // barriers and LDS round trips, nothing to overlap inside the workgroup
   const uint32_t tid = threadIdx.x;
-  const uint32_t n = min(ctl->pool_n, cap);
+  // sweep_coop: candidates settled through bitmaps wait in the pool's last kAdmMax slots (the scans then fill only
+  // the slots in front of them): moved up behind the scans' keys first
+  const uint32_t an = min(ctl->adm_n, cap - scan_cap);
+  uint32_t n = min(ctl->pool_n, scan_cap);
+  if (an) {                                           // (uniform)
+    const unsigned long long key = tid < an ? pool[scan_cap + tid] : 0ull;
+    __syncthreads();
+    if (tid < an) pool[n + tid] = key;
+    if (tid == 0) ctl->adm_n = 0;
+    __syncthreads();
+    n += an;
+  }
   if (n <= kRankSortMax) {
     // Small pools (most of them): every key counts the keys below it -- the keys are distinct,
     // a rank being harvested once -- and the best `keep` go straight to their places: three
@@ -618,14 +630,15 @@ __device__ __forceinline__ uint32_t matches_needed(unsigned long long thr, uint3
 // 7:4; 0: none) -- a harvested counter of such a window holds the matches among the counted slices only, `need` was
 // lowered by the publishing wave accordingly, and the candidate does NOT enter the pool here: if its best case
 // (every left-out slice a match) beats the threshold it goes to the step's PENDING list as in-window rank | parity
-// << 16 | counted matches << 20, and sweep_coop settles it through the left-out slices' bitmaps a step later.
+// << 16 | counted matches << 20, and sweep_coop's manager wave settles it through those slices' bitmaps during the next
+// step.  `stride`: the threads that scan (sweep_coop's worker waves: NT - 64).
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const uint32_t need, const uint32_t cap,
                                           const unsigned long long* thr_p, const unsigned long long* floor,
                                           const uint32_t* tomb, unsigned long long* pool, const uint32_t pool_cap,
                                           uint32_t* pool_n, uint32_t* overflow, uint32_t wbase, uint32_t wlen,
                                           uint32_t* path_flag = nullptr, const uint32_t ls = 0, uint32_t* pend = nullptr,
-                                          uint32_t* pend_n = nullptr, const uint32_t pend_cap = 0) {
+                                          uint32_t* pend_n = nullptr, const uint32_t pend_cap = 0, const uint32_t stride = NT) {
   using P = Packing<CT>;
   using S = ScanTraits<CT>;
   const uint32_t tid = threadIdx.x;
@@ -684,7 +697,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
     // slower in round 1; all four of a thread in flight, round 3: 7.5 % slower (330.2 vs 307.4 ms per 500 k needles,
     // same box): the LDS pipe is what the two resident workgroups share, a burst of reads lengthens the queue the
     // other one's atomics wait in; read-and-clear in one ds_wrxchg_rtn_b64 per 8 bytes: +0.5 %, noise.)
-    for (uint32_t i = tid; i < nvec; i += NT) {
+    for (uint32_t i = tid; i < nvec; i += stride) {
       uint4 v = cnt128[i];
       cnt128[i] = zq;
       v = S::mask_pad(v, i);
@@ -696,7 +709,7 @@ __device__ __forceinline__ void scan_core(uint4* cnt128, const Needle& nd, const
     }
   } else {
     // nothing in this window can enter the pool any more: just clear the counters
-    for (uint32_t i = tid; i < nvec; i += NT) cnt128[i] = zq;
+    for (uint32_t i = tid; i < nvec; i += stride) cnt128[i] = zq;
   }
   S::clear_unreached_pad(cnt128, nvec, tid);
   __builtin_amdgcn_s_setprio(0);
@@ -739,7 +752,8 @@ __device__ __forceinline__ uint32_t cold_start_need(const uint4* cnt128, uint32_
 template <typename CT, int NT>
 __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd, uint4* cnt128,
                                             unsigned long long* pool, Control* ctl, uint32_t wbase,
-                                            uint32_t wlen) {
+                                            uint32_t wlen, uint32_t pool_cap = 0) {
+  if (pool_cap == 0) pool_cap = A.pool_cap;
   const unsigned long long thr = ctl->thr;
   uint32_t need_floor = 0;
   // (not with a floor key or tombstones: candidates they reject would be counted as present)
@@ -748,7 +762,7 @@ __device__ __forceinline__ void scan_window(const FindArgs& A, const Needle& nd,
     PATH_FLAG(A, nd.q, kPathColdStart);
   }
   scan_core<CT, NT>(cnt128, nd, max(matches_needed(thr, nd.T, wbase), need_floor), min(nd.T, ScanTraits<CT>::kMaxCount),
-                    &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n, &ctl->overflow, wbase, wlen,
+                    &ctl->thr, &ctl->floor, A.tomb, pool, pool_cap, &ctl->pool_n, &ctl->overflow, wbase, wlen,
                     STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
 }
 
@@ -769,15 +783,15 @@ __device__ __forceinline__ uint32_t select_at(const FindArgs& A) {
 // overflowed during the scan of this window, i.e. the window has to be swept again.
 template <int NT>
 __device__ __forceinline__ bool select_after_scan(const FindArgs& A, unsigned long long* pool, Control* ctl,
-                                                  uint32_t wbase, uint32_t wlen, uint32_t q_flag) {
+                                                  uint32_t wbase, uint32_t wlen, uint32_t q_flag, uint32_t scan_cap = 0) {
   (void)q_flag;
   const uint32_t ov = ctl->overflow;
-  const uint32_t pn = ctl->pool_n;
+  const uint32_t pn = ctl->pool_n + ctl->adm_n;       // (settled candidates in the pool's tail count)
   // compact when the pool holds more than select_at() keys -- or as soon as it holds `keep` candidates for the first
   // time, so that a threshold exists from then on
   if (!(ov || pn > select_at(A) || (ctl->thr == kKeyInf && pn >= A.keep))) return false;
   if (STATS(A) && threadIdx.x == 0) atomicAdd(&STATS(A)[kStatCompactions], 1ull);
-  compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+  compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, scan_cap);
   PATH_FLAG(A, q_flag, ov ? kPathCompaction | kPathResweep : kPathCompaction);
   if (!ov) return false;
   // The pool overflowed mid-window: candidates of this window were lost.  Keep the
@@ -835,7 +849,7 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
   for (uint32_t w = w0; w < w1; ++w) {
     const uint32_t wbase = w * kWindowRanks;
     const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
-    const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
+    const uint2* soff = A.slice_se + size_t(w) * kNumCodes;
     bool redo;
     do {
       redo = false;
@@ -844,8 +858,8 @@ __device__ void sweep_chunked(const FindArgs& A, const Needle& nd, const uint16_
         const uint32_t tc = min(kCodeChunk, nd.T - c0);
         if (tid < tc) {
           const uint32_t code = codes[c0 + tid];
-          const uint32_t sb_ = soff[code + 1];
-          s_a[tid] = postings_start(soff[code], sb_, A.dense_min8); s_b[tid] = sb_;
+          const uint2 se_ = soff[code];
+          s_a[tid] = se_.x; s_b[tid] = se_.y;
         }
         __syncthreads();
         touched |= count_window<CT, kNW>(A, cnt32, s_a, s_b, tc, wid, lane);
@@ -953,9 +967,9 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
   do {                                                                           \
     A0 = B0 = A1 = B1 = 0;                                                       \
     if ((w_) < nwin) {                                                           \
-      const uint32_t* soff_ = A.slice_off + size_t(w_) * kNumCodes;              \
-      if (own0) { B0 = soff_[code0 + 1]; A0 = postings_start(soff_[code0], B0, A.dense_min8); } \
-      if (own1) { B1 = soff_[code1 + 1]; A1 = postings_start(soff_[code1], B1, A.dense_min8); } \
+      const uint2* soff_ = A.slice_se + size_t(w_) * kNumCodes;                  \
+      if (own0) { const uint2 se_ = soff_[code0]; A0 = se_.x; B0 = se_.y; }      \
+      if (own1) { const uint2 se_ = soff_[code1]; A1 = se_.x; B1 = se_.y; }      \
     }                                                                            \
   } while (0)
 
@@ -1054,8 +1068,7 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // itself (BLURRILY_COUNT_WALK).
 constexpr uint32_t kRingUnitsMax = 512;
 __host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) {
-  return pool_cap <= 512 ? kRingUnitsMax : 256u;       // (multiples of the sixteen waves; a 1 024-entry pool had 384
-                                                       //  units through round 3: the pending lists took the difference)
+  return pool_cap <= 512 ? kRingUnitsMax : pool_cap <= 1024 ? 384u : 256u;       // (multiples of the sixteen waves)
 }
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two
 // row broadcasts of gfx9): ten VALU instructions, against six dependent ds_bpermute round trips for __shfl_up.
@@ -1072,37 +1085,50 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
 }
 
 struct UnitRing {
-  // what a step starts with, ONE 8-byte read: .x the step the slot's units belong to (past the end: none left),
-  // .y the number of units (kRingWalk: too many, walk the table) | the scan's admission bound << 16 (0: the slow
-  // scan, which works it out itself -- cold start)
+  // what a step starts with, ONE 8-byte read: .x the step the slot's units belong to (past the end: none left);
   // .y = units (bits 15:0; kRingWalk: too many, walk the table) | the scan's admission bound << 16 (bits 23:16;
   // 0: the slow scan, which works it out itself -- cold start) | slices left out of the even window's count << 24
   // (bits 27:24) | of the odd window's << 28
   uint2    hdr[2];
-  uint32_t visit[2];                                            // the visit index chosen most recently, by turns
+  uint32_t visit[2];                                            // (sweep_coop_plain: the visit index chosen most recently, by turns)
   uint32_t pad_[2];
   // per step (e & 3: a step's candidates are settled while the step after the next is being published) and window
   // parity: where the postings of the slices LEFT OUT of the count start in `ent` (their bitmaps sit in front of them)
   uint32_t hot[4][2][8];
-  // behind it: desc[2][ring_units_for(pool_cap)], .x first entry of the unit, .y end of its slice
+  // behind it: desc[2][ring_units_for(pool_cap)], .x first entry of the unit, .y end of its slice; pend[2][kPendMax]
 };
 __device__ __forceinline__ uint2* ring_slot(UnitRing* ring, uint32_t slot, uint32_t ring_units) {
   return reinterpret_cast<uint2*>(ring + 1) + (slot ? ring_units : 0u);
 }
 constexpr uint32_t kRingWalk = 0xFFFFu;
 constexpr uint32_t kNmMaxLeftOut = 8;                           // slices left out of one window's count at most (UnitRing::hot)
-// candidates of one step waiting for their bitmap words, per ring slot: behind the descriptors in the dynamic LDS
-constexpr uint32_t kPendMax = 256;
+// the pending lists: behind the descriptors in the dynamic LDS
 __device__ __forceinline__ uint32_t* pend_list(UnitRing* ring, uint32_t slot, uint32_t ring_units) {
   return reinterpret_cast<uint32_t*>(reinterpret_cast<uint2*>(ring + 1) + 2 * ring_units) + slot * kPendMax;
 }
-static_assert(kRingUnitsMax < kRingWalk, "a unit count is sixteen bits of the step header");
+
+// sweep_coop leaves slices out of a step's count only where the candidates that leaves pending are sure of their
+// place in the pool (sweep_role); the pool's last kAdmMax slots are then theirs
+__device__ __forceinline__ bool coop_can_leave(const FindArgs& A) {
+  return A.nm_cmin != 0 && A.pool_cap <= 512 && !A.own_only && select_at(A) + 32 <= kAdmMax;
+}
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight
+// (s_waitcnt vmcnt(0)): behind a step's count that is the manager's table of the step after the next, just requested,
+// behind its scan a worker's first unit of the next step -- loads that are meant to travel across the barriers.  The
+// waves of a sweep exchange data through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // why sweep_coop's hot loop was left
 enum : uint32_t { kLeftDone = 0, kLeftWalk = 1, kLeftSlowScan = 2, kLeftSelect = 3 };
 
+// ---- cooperative flavour, every wave doing everything (rounds 2-3; since round 4 the sweep of launches that leave
+// nothing out of a step's count: limits above 64, phase 1 of the window-major sweep, "nm_cmin" 0) ---------------------
+// ONE wave per step (rotating) cuts the slices of the next visited window into units and publishes them as
+// descriptors {first entry, slice end} in an LDS ring; in the next step every wave reads the descriptors of its units
+// (unit k belongs to wave k mod kNW) and streams them, one unit's LDS atomics running under the next unit's load.
 template <typename CT, int NT>
-__device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
+__device__ void sweep_coop_plain(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
                            unsigned long long* pool, Control* ctl, UnitRing* ring, const uint8_t* wmt,
                            const uint32_t w0, const uint32_t w1, const uint32_t ws) {
   // A step covers kWPS windows: one with byte counters, two with 4-bit counters (CT = Nib).  Lane
@@ -1155,11 +1181,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (STATS(A) && w_ < w1) st_tab += 2u * tc * (kNib && w_ + 1 < w1 ? 2u : 1u); \
     if (w_ < w1 && own) {                                                        \
       const uint32_t idx_ = w_ * kNumCodes + code;                               \
-      B0 = A.slice_off[idx_ + 1]; A0 = postings_start(A.slice_off[idx_], B0, A.dense_min8); \
+      const uint2 se_ = A.slice_se[idx_]; A0 = se_.x; B0 = se_.y;                \
     }                                                                            \
     if (kNib && w_ + 1 < w1 && own) {                                            \
       const uint32_t idx_ = (w_ + 1) * kNumCodes + code;                         \
-      B1 = A.slice_off[idx_ + 1]; A1 = postings_start(A.slice_off[idx_], B1, A.dense_min8); \
+      const uint2 se_ = A.slice_se[idx_]; A1 = se_.x; B1 = se_.y;                \
     }                                                                            \
   } while (0)
   // The header of step step_ in ring slot s_, by lane 0 of the publishing wave: the step, its unit count and the
@@ -1168,9 +1194,12 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // the step in between), so the published bound is at most too low: the scan then looks at a few counters more,
   // and every counter it looks at is tested against the threshold of the moment before it enters the pool.
   // 0 = no threshold yet and a cold start due: the slow scan.
-#define BLURRILY_PUBLISH_HDR(s_, step_, nu_, need_, ls_)                         \
+#define BLURRILY_PUBLISH_HDR(s_, step_, nu_)                                     \
   do {                                                                           \
-    if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | ((need_) << 16) | ((ls_) << 24)); \
+    const unsigned long long thr_ = ctl->thr;                                    \
+    uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFFFu); \
+    if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
+    if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | (need_ << 16));   \
   } while (0)
   // (A window in which fewer of the needle's trigrams occur AT ALL than a candidate needs, left out by the publishing
   // wave -- two ballots over the table it holds -- measured in round 3: 255.5 vs 252.9 ms, 1 % slower: at Geonames
@@ -1180,47 +1209,13 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // wave by wave, so that ONE read -- lane j the wave's j-th unit -- hands a wave all its descriptors of a step.
 #define BLURRILY_UNIT_AT(k_) (((k_) & (kNW - 1)) * ring_rows + (k_) / kNW)
 #define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + min(lane, ring_rows - 1)])
-  // LEFT OUT of the count (round 4; the MaxScore argument of wsweep_kernel, inside the needle-major step): once the
-  // needle has a threshold -- `need_` matches to enter its top `keep` in this step's windows -- the l_max_ = need_ -
-  // nm_cmin LARGEST slices of at least nm_dense postings of a window need not be counted.  A reference with need_
-  // matches has at least need_ - L of them among the counted slices, so the scan finds it with the bound lowered by
-  // L, and its exact count is settled from the left-out slices' bitmaps where it is harvested (scan_core).  Lane t
-  // ranks its slice among the window's dense ones by size (one readlane per dense slice); the chosen ones publish
-  // where their postings start (UnitRing::hot) and list no units.
-#define BLURRILY_LEAVE_OUT(hs_, h_, A_, B_, units_)                              \
+#define BLURRILY_PRODUCE(s_, step_, A0, B0, A1, B1)                              \
   do {                                                                           \
-    const uint32_t size_ = (B_) - (A_);                                          \
-    const bool dense_ = size_ >= A.nm_dense;                                     \
-    uint32_t bigger_ = 0;                                                        \
-    for (unsigned long long m_ = __ballot(dense_); m_; m_ &= m_ - 1) {           \
-      const uint32_t u_ = __builtin_ctzll(m_);                                   \
-      const uint32_t su_ = __builtin_amdgcn_readlane(size_, u_);                 \
-      bigger_ += (su_ > size_ || (su_ == size_ && u_ < lane)) ? 1u : 0u;         \
-    }                                                                            \
-    const bool skip_ = dense_ && bigger_ < l_max_;                               \
-    const unsigned long long sm_ = __ballot(skip_);                              \
-    if (skip_) {                                                                 \
-      ring->hot[hs_][h_][__popcll(sm_ & ((1ull << lane) - 1ull))] = (A_);        \
-      units_ = 0;                                                                \
-    }                                                                            \
-    ls_ |= uint32_t(__popcll(sm_)) << (4u * (h_));                               \
-  } while (0)
-#define BLURRILY_PRODUCE(s_, hs_, step_, A0, B0, A1, B1)                         \
-  do {                                                                           \
-    const unsigned long long thr_ = ctl->thr;                                    \
-    uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFu); \
-    uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
-    uint32_t ls_ = 0;                                                            \
-    const uint32_t l_max_ = (thr_ != kKeyInf && A.nm_cmin != 0 && need_ > A.nm_cmin) ? min(need_ - A.nm_cmin, kNmMaxLeftOut) : 0u; \
-    if (l_max_) {                                                                \
-      BLURRILY_LEAVE_OUT(hs_, 0u, A0, B0, units0_);                              \
-      if (kNib) BLURRILY_LEAVE_OUT(hs_, 1u, A1, B1, units1_);                    \
-    }                                                                            \
-    if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
+    const uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
     const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
-    if (total_ > ring_units) {                 /* every wave walks the table: ALL slices, nothing left out */ \
-      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk, need_, 0u);                     \
+    if (total_ > ring_units) {                                                   \
+      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk);                                \
     } else {                                                                     \
       uint2* const slot_ = ring_slot(ring, s_, ring_units);                      \
       uint32_t at_ = incl_ - units0_ - units1_;                                  \
@@ -1228,10 +1223,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
         slot_[BLURRILY_UNIT_AT(at_)] = make_uint2(A0 + j_ * 512, B0);            \
       for (uint32_t j_ = 0; j_ < units1_; ++j_, ++at_)                           \
         slot_[BLURRILY_UNIT_AT(at_)] = make_uint2((A1 + j_ * 512) | 1u, B1);     \
-      /* the scan's bound, lowered by the most slices either window leaves out (a harvested counter is settled  \
-         exactly, so a bound that is too low for the other window costs a look, nothing else) */ \
-      const uint32_t lmost_ = max(ls_ & 15u, ls_ >> 4);                          \
-      BLURRILY_PUBLISH_HDR(s_, step_, total_, need_ - min(need_, lmost_), ls_);  \
+      BLURRILY_PUBLISH_HDR(s_, step_, total_);                                   \
     }                                                                            \
   } while (0)
   // The units of ring slot s_ that belong to this wave (k = wid, wid + kNW, ...): one unit's LDS
@@ -1308,67 +1300,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
                               { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); \
                                 if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
   } while (0)
-  // ---- settling a step's PENDING candidates (slices were left out of its count) a step later ---------------------
-  // The scan of step e leaves them in pend_list(e & 1): in-window rank | parity << 16 | counted matches << 20.  Behind
-  // the scan barrier thread j takes the pair (candidate j >> sh, left-out slice j & (2^sh - 1)) and REQUESTS the word of
-  // that slice's bitmap holding the candidate's bit (PROBE_ISSUE); the word travels under step e + 1's count; in
-  // front of that step's count barrier the thread adds its bit to the candidate's entry (PROBE_SETTLE: one LDS
-  // atomic), behind the barrier thread c reads entry c -- now the candidate's exact match count -- and admits it to the
-  // pool, or not, like any harvested counter (PROBE_ADMIT).  No barrier of its own, no load latency on the step's
-  // critical path; two VGPRs (word, bit | candidate) live across the count.  The pairs go to the wave that is
-  // farthest from a turn (rt_: the thread's number counted from that wave's first lane).
-#define BLURRILY_PROBE_ISSUE(slot_, hs_, np_, ls_, rt_)                          \
-  do {                                                                           \
-    pmeta = 0;                                                                   \
-    const uint32_t lm_ = max((ls_) & 15u, (ls_) >> 4);                           \
-    const uint32_t sh_ = lm_ > 4u ? 3u : lm_ > 2u ? 2u : lm_ > 1u ? 1u : 0u;     \
-    if (((rt_) & ~63u) < ((np_) << sh_)) {               /* (wave-uniform) */    \
-      const uint32_t c_ = (rt_) >> sh_, i_ = (rt_) & ((1u << sh_) - 1u);         \
-      if (c_ < (np_)) {                                                          \
-        const uint32_t e_ = pend_list(ring, slot_, ring_units)[c_];              \
-        const uint32_t h_ = (e_ >> 16) & 1u;                                     \
-        if (i_ < (((ls_) >> (4u * h_)) & 15u)) {                                 \
-          const uint32_t base_ = ring->hot[hs_][h_][i_];                         \
-          pv = reinterpret_cast<const uint32_t*>(A.ent + (base_ - kBitmapSlots))[(e_ & 0xFFFFu) >> 5]; \
-          pmeta = 0x80000000u | (c_ << 5) | (e_ & 31u);                          \
-        }                                                                        \
-      }                                                                          \
-      if (STATS(A)) st_probe += __popcll(__ballot(pmeta != 0));                  \
-    }                                                                            \
-  } while (0)
-#define BLURRILY_PROBE_SETTLE(slot_)                                             \
-  do {                                                                           \
-    if (pmeta != 0 && ((pv >> (pmeta & 31u)) & 1u) != 0)                         \
-      __hip_atomic_fetch_add(&pend_list(ring, slot_, ring_units)[(pmeta >> 5) & 0xFFFFu], 1u << 20, __ATOMIC_RELAXED, \
-                             __HIP_MEMORY_SCOPE_WORKGROUP);                      \
-    pmeta = 0;                                                                   \
-  } while (0)
-#define BLURRILY_PROBE_ADMIT(slot_, np_, pstep_, rt_)                            \
-  do {                                                                           \
-    if (((rt_) & ~63u) < (np_)) {                        /* (wave-uniform) */    \
-      if ((rt_) < (np_)) {                                                       \
-        const uint32_t e_ = pend_list(ring, slot_, ring_units)[rt_];             \
-        const uint32_t rank_ = (pstep_) * kWPS * kWindowRanks + ((e_ >> 16) & 1u) * kWindowRanks + (e_ & 0xFFFFu); \
-        const unsigned long long key_ = (static_cast<unsigned long long>(tc - min(tc, e_ >> 20)) << 32) | rank_; \
-        bool pass_ = key_ <= ctl->thr;                                           \
-        if (nd.has_floor) pass_ = pass_ && key_ > ctl->floor;                    \
-        if (pass_) {                                     /* (tombstones were looked at where it was harvested) */ \
-          const uint32_t at_ = atomicAdd(&ctl->pool_n, 1u);                      \
-          if (at_ < A.pool_cap) pool[at_] = key_; else ctl->overflow = 1;        \
-        }                                                                        \
-      }                                                                          \
-      if ((rt_) == 0) ctl->pend_n[slot_] = 0;                                    \
-    }                                                                            \
-  } while (0)
-  // the same at once, for the rare paths: nothing stays in flight across them
-#define BLURRILY_PROBE_DRAIN(slot_, hs_, np_, ls_, pstep_)                       \
-  do {                                                                           \
-    BLURRILY_PROBE_ISSUE(slot_, hs_, np_, ls_, tid);                             \
-    BLURRILY_PROBE_SETTLE(slot_);                                                \
-    __syncthreads();                                                             \
-    BLURRILY_PROBE_ADMIT(slot_, np_, pstep_, tid);                               \
-    __syncthreads();                                                             \
-  } while (0)
 #define BLURRILY_PRODUCER(e_) ((e_) & (kNW - 1))              /* the publishing turn goes round the waves */
   // The two turns a step has behind its units.  The wave whose turn it is publishes the next visited step (its
   // table arrived a step ago); the wave after it chooses the step after the next (the threshold only changes
@@ -1378,7 +1309,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     if (wid == BLURRILY_PRODUCER((e_) + 1)) {                                    \
       __builtin_amdgcn_s_setprio(3);                /* the wave the count barrier waits for goes first */ \
       if (my_i < n_visit) {                                                      \
-        BLURRILY_PRODUCE((s_) ^ 1u, ((e_) + 1u) & 3u, BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1); \
+        BLURRILY_PRODUCE((s_) ^ 1u, BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1);   \
       } else if (lane == 0) {                                                    \
         ring->hdr[(s_) ^ 1u] = make_uint2(v1, 0u);                               \
       }                                                                          \
@@ -1399,9 +1330,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   const uint32_t lane8 = lane * 8, lane16 = lane * 16;
   uint32_t ta = 0, tb = 0, ta1 = 0, tb1 = 0;                    // table this wave will publish next
   PHASE_DECL;
-  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0, st_probe = 0;   // request counters (FindArgs::stats), wave-uniform
-  uint32_t pv = 0, pmeta = 0;                                   // a bitmap word on its way, and whose bit it holds (PROBE_*)
-  uint32_t np_prev = 0, p_prev = 0;                             // the step before: its pending candidates, its step
+  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0;    // request counters (FindArgs::stats), wave-uniform
   // Which step comes next is decided by ONE wave per step -- the one that then fetches that step's table --
   // and travels through LDS with the units (`hdr[slot]`; the visit index chosen last in `visit[]`).  The other
   // fifteen waves read one header per step instead of each running the window-bound loop, the 64-bit threshold
@@ -1410,7 +1339,7 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
   if (wid == BLURRILY_PRODUCER(0u)) {
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
-    BLURRILY_PRODUCE(0u, 0u, BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
+    BLURRILY_PRODUCE(0u, BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
   }
   if (wid == BLURRILY_PRODUCER(1u)) {
     BLURRILY_NEXT_VISIT(1u, my_i);
@@ -1435,11 +1364,11 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   // need is not held in registers, nor worked out, step after step.
   uint32_t e = 0;
   for (;;) {
-    uint32_t left, s, p, n_units, hy_, np_cur = 0;
+    uint32_t left, s, p, n_units;
     for (;; ++e) {
       s = e & 1;
       p = __builtin_amdgcn_readfirstlane(h_next.x);
-      hy_ = __builtin_amdgcn_readfirstlane(h_next.y);
+      const uint32_t hy_ = __builtin_amdgcn_readfirstlane(h_next.y);
       n_units = hy_ & 0xFFFFu;
       if (p >= v1) { left = kLeftDone; break; }                 // no step left
       ++st_steps;
@@ -1451,9 +1380,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       BLURRILY_COUNT_UNITS(s, n_units, true);
       PHASE_MARK(2);                                            // units counted
       BLURRILY_TAKE_TURNS(e, s);
-      // (the thread's number counted from the first lane of the wave farthest from a turn)
-      const uint32_t rt = (tid - 64u * ((e + 9u) & (kNW - 1))) & uint32_t(NT - 1);
-      if (np_prev) BLURRILY_PROBE_SETTLE(s ^ 1u);               // the step before's candidates: the bits have arrived
       __syncthreads();                                          // counts and next descriptors visible
       PHASE_MARK(3);                                            // barrier after count
       // The next step's header and this wave's units of it were published before that barrier: requested now,
@@ -1461,21 +1387,13 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // other workgroup's atomics), between the scan barrier and the first load of the next step.
       h_next = ring->hdr[s ^ 1u];
       d_mine = BLURRILY_MY_UNITS(s ^ 1u);
-      if (np_prev) { BLURRILY_PROBE_ADMIT(s ^ 1u, np_prev, p_prev, rt); np_prev = 0; }
       if (n_units == 0) continue;                               // nothing of the needle in this step's windows
-      const uint32_t need = (hy_ >> 16) & 0xFFu;
+      const uint32_t need = hy_ >> 16;
       if (need == 0) { left = kLeftSlowScan; break; }
       const uint32_t wbase = p * kWPS * kWindowRanks;
       const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-      const uint32_t ls = hy_ >> 24;
-      {
-        // (a pair per thread: the pending list holds what the threads can settle)
-        const uint32_t lm = max(ls & 15u, ls >> 4);
-        const uint32_t pend_cap = min(kPendMax, uint32_t(NT) >> (lm > 4u ? 3u : lm > 2u ? 2u : lm > 1u ? 1u : 0u));
-        scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n,
-                          &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr,
-                          ls, pend_list(ring, s, ring_units), &ctl->pend_n[s], pend_cap);
-      }
+      scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, A.pool_cap, &ctl->pool_n,
+                        &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr);
       BLURRILY_PRELOAD();
       PHASE_MARK(5);                                            // scan
       __syncthreads();                                          // counters are zero again
@@ -1483,22 +1401,9 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       // (Looking at the pool a count phase later -- the read requested here, used behind the next count barrier, a
       // compaction then running with the next step counted and not yet scanned -- was built and measured in round 3:
       // 2 % slower, 293.0 vs 287.2 ms per 500 k needles; the thresholds the headers carry are a step staler.)
-      const uint4 c_ = *reinterpret_cast<const uint4*>(&ctl->pool_n);          // pool_n, overflow, pend_n[0], pend_n[1]
+      const uint2 c_ = *reinterpret_cast<const uint2*>(&ctl->pool_n);          // pool_n, overflow
       const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x), ov_ = __builtin_amdgcn_readfirstlane(c_.y);
-      np_cur = __builtin_amdgcn_readfirstlane(s ? c_.w : c_.z);
       if (ov_ != 0 || pn_ > sel_at || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
-      if (np_cur) {                                             // this step's candidates: their bitmap words requested
-        BLURRILY_PROBE_ISSUE(s, e & 3u, np_cur, ls, rt);
-        np_prev = np_cur; p_prev = p;
-      }
-    }
-    // candidates of the step before whose words are under way (the loop was left in front of a count): settled now
-    if (np_prev) {
-      BLURRILY_PROBE_SETTLE((e & 1u) ^ 1u);
-      __syncthreads();
-      BLURRILY_PROBE_ADMIT((e & 1u) ^ 1u, np_prev, p_prev, tid);
-      __syncthreads();
-      np_prev = 0;
     }
     if (left == kLeftDone) break;
     // ---- the rare paths of step p ----------------------------------------------------------------
@@ -1514,18 +1419,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
     }
     // kLeftSelect: the step is scanned, select_after_scan finds the pool as the hot loop saw it; else: scan first
     bool scanned = left == kLeftSelect;
-    if (scanned && np_cur) {
-      // the step's own pending candidates: settled at once -- unless the pool (or their list) overflowed: the step is
-      // then swept again with every slice counted, and they would come twice
-      if (ctl->overflow) {
-        __syncthreads();                                        // (everybody has read the flag)
-        if (tid == 0) ctl->pend_n[s] = 0;
-        __syncthreads();
-      } else {
-        BLURRILY_PROBE_DRAIN(s, e & 3u, min(np_cur, kPendMax), hy_ >> 24, p);
-      }
-      np_cur = 0;
-    }
     for (;;) {
       if (!scanned) {
         scan_window<CT, NT>(A, nd, cnt128, pool, ctl, wbase, wlen);
@@ -1533,8 +1426,8 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
       }
       scanned = false;
       if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q)) break;
-      ++st_redo;                                                // pool overflow: sweep step p again -- every slice of it
-      if (n_units == kRingWalk || (hy_ >> 24) != 0) BLURRILY_COUNT_WALK(p);   // (the ring lists no units of left-out slices)
+      ++st_redo;                                                // pool overflow: sweep step p again
+      if (n_units == kRingWalk) BLURRILY_COUNT_WALK(p);
       else BLURRILY_COUNT_UNITS(s, n_units, false);
       __syncthreads();
     }
@@ -1547,7 +1440,6 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   if (STATS(A) && lane == 0) {
     atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
     atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
-    atomicAdd(&STATS(A)[kStatProbes], static_cast<unsigned long long>(st_probe));
     if (wid == 0) {
       atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
       atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
@@ -1558,15 +1450,10 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
   __syncthreads();                                              // ring and ctl quiet before the needle ends
 #undef BLURRILY_TAKE_TURNS
 #undef BLURRILY_PRODUCER
-#undef BLURRILY_PROBE_DRAIN
-#undef BLURRILY_PROBE_ADMIT
-#undef BLURRILY_PROBE_SETTLE
-#undef BLURRILY_PROBE_ISSUE
 #undef BLURRILY_COUNT_WALK
 #undef BLURRILY_COUNT_UNITS
 #undef BLURRILY_PRELOAD
 #undef BLURRILY_PRODUCE
-#undef BLURRILY_LEAVE_OUT
 #undef BLURRILY_MY_UNITS
 #undef BLURRILY_UNIT_AT
 #undef BLURRILY_PUBLISH_HDR
@@ -1576,13 +1463,475 @@ __device__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* 
 #undef BLURRILY_STEP_AT
 }
 
+
+// One needle's sweep as ONE of two roles (round 4).  Through round 3 every wave of the workgroup did everything: its
+// share of a step's units, its share of the scan -- and, by turns, the choosing of the next step, the fetching of
+// its slice table and the publishing of its units, so that every wave held the table's registers and the turns' code,
+// and the wave with a turn, which took it BEHIND its own units, was the one the count barrier waited for.  Now the
+// workgroup's last wave is the MANAGER: it chooses, fetches and publishes (and, since this round, decides which dense
+// slices a step leaves out of its count and settles the candidates that leaves pending) while the fifteen WORKERS
+// count -- and counts and scans nothing itself; the workers count, scan and glance at the pool, and hold none of the
+// manager's state.  Both roles run the same sequence of barriers and leave their hot loops on the same, uniform
+// conditions (the step's header, the pool's state behind a scan); the rare paths behind the loops are common code.
+// The two are separate instantiations called from disjoint branches, so that what one role keeps in registers is not
+// live in the other's loop (every attempt of this round to add the left-out slices' bookkeeping to the shared loop cost
+// 6-17 % with NOTHING left out: 64 VGPRs, two workgroups a CU).
+template <typename CT, int NT, bool MANAGER>
+__device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
+                                           unsigned long long* pool, Control* ctl, UnitRing* ring, const uint8_t* wmt,
+                                           const uint32_t w0, const uint32_t w1, const uint32_t ws) {
+  // A step covers kWPS windows: one with byte counters, two with 4-bit counters (CT = Nib).  Lane
+  // t of the table holds trigram t's slice of the step's window -- of both windows with 4-bit
+  // counters (second slot) -- and a unit's descriptor carries its window's parity in bit 0.
+  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  constexpr uint32_t kWPS = kNib ? 2 : 1;
+  constexpr uint32_t kNW = NT / 64, kWorkers = kNW - 1;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wid = MANAGER ? kWorkers : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tc = nd.T;                                     // <= 64
+  const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
+  const uint32_t n_visit = v1 - v0;
+  uint4* const cnt128 = reinterpret_cast<uint4*>(cnt32);
+  const uint32_t ring_units = ring_units_for(A.pool_cap), ring_rows = ring_units / kNW;   // rows: units of a wave
+  const uint32_t ring_cap = kWorkers * ring_rows;               // units a slot lists (the manager's rows stay empty)
+  // Slices are left out of a step's count only where the candidates that leaves pending are sure of their place in the
+  // pool: limits up to 64 (the 512-entry pool), its last kAdmMax slots theirs alone, a step's pending list no longer than
+  // what those slots hold beside the keys a glance lets pass (select_at()); not in phase 1 of the window-major sweep.
+  const uint32_t sel_at = select_at(A);
+  const bool can_leave = coop_can_leave(A);
+  const uint32_t scan_pool_cap = can_leave ? A.pool_cap - kAdmMax : A.pool_cap;
+  const uint32_t pend_cap = can_leave ? min(kPendMax, kAdmMax - sel_at) : 0u;
+  // (the i-th step visited: upward from the needle's own length class, round the end.  Outward from it instead --
+  // one step above, one below, by turns -- measured in round 3: 270.0 vs 253.2 ms per 500 k needles, 6.7 % slower;
+  // downward from it, round the start: 292.7 ms, 16 % slower -- every window visited later lies BEHIND the threshold's
+  // rank when the sweep goes upward, and needs one match more)
+#define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
+  // most trigrams of the needle a reference of the step's window(s) can hold
+#define BLURRILY_WMT_AT(i_, out_)                                                \
+  do {                                                                           \
+    const uint32_t p_ = min(BLURRILY_STEP_AT(i_), v1 - 1) * kWPS;                \
+    if (wmt) {                       /* the workgroup's LDS copy (clamped to 255 >= tc): no global round trip */ \
+      out_ = wmt[p_];                                                            \
+      if (kNib && p_ + 1 < w1) out_ = max(out_, uint32_t(wmt[p_ + 1]));          \
+    } else {                                                                     \
+      out_ = A.win_max_tri[p_];                                                  \
+      if (kNib && p_ + 1 < w1) out_ = max(out_, A.win_max_tri[p_ + 1]);          \
+    }                                                                            \
+  } while (0)
+  // first visit index >= from_ whose step can hold a candidate (n_visit: none)
+#define BLURRILY_NEXT_VISIT(from_, out_)                                         \
+  do {                                                                           \
+    out_ = (from_);                                                              \
+    while (out_ < n_visit) {                                                     \
+      uint32_t m_;                                                               \
+      BLURRILY_WMT_AT(out_, m_);                                                 \
+      if (min(tc, m_) >= matches_needed(ctl->thr, tc, BLURRILY_STEP_AT(out_) * kWPS * kWindowRanks)) break; \
+      ++out_;                                                                    \
+    }                                                                            \
+  } while (0)
+  // slice table of step p_ (lane t: the needle's trigram code_): (A0, B0) the (even) window, (A1, B1) the odd one
+  // with 4-bit counters; a dense slice's postings start behind its bitmap (postings_start)
+#define BLURRILY_FETCH_TABLE(p_, code_, A0, B0, A1, B1)                          \
+  do {                                                                           \
+    A0 = B0 = A1 = B1 = 0;                                                       \
+    const uint32_t w_ = (p_) * kWPS;                                             \
+    if (STATS(A) && w_ < w1) st_tab += 2u * tc * (kNib && w_ + 1 < w1 ? 2u : 1u); \
+    if (w_ < w1 && lane < tc) {                                                  \
+      const uint32_t idx_ = w_ * kNumCodes + (code_);                            \
+      const uint2 se_ = A.slice_se[idx_]; A0 = se_.x; B0 = se_.y;                \
+    }                                                                            \
+    if (kNib && w_ + 1 < w1 && lane < tc) {                                      \
+      const uint32_t idx_ = (w_ + 1) * kNumCodes + (code_);                      \
+      const uint2 se_ = A.slice_se[idx_]; A1 = se_.x; B1 = se_.y;                \
+    }                                                                            \
+  } while (0)
+  // The header of step step_ in ring slot s_, by lane 0 of the manager: the step, its unit count, the bound its scan
+  // admits counters from -- worked out HERE, once, from the threshold as it is now, instead of by every wave behind
+  // the count barrier -- and how many slices each of its windows leaves out of the count.  The threshold can only
+  // tighten until that scan runs (in the select of the step in between), so the published bound is at most too low:
+  // the scan then looks at a few counters more, and every counter it looks at is tested against the threshold of the
+  // moment before it enters the pool.  A bound of 0 = no threshold yet and a cold start due: the slow scan.
+#define BLURRILY_PUBLISH_HDR(s_, step_, nu_, need_, ls_)                         \
+  do {                                                                           \
+    if (lane == 0) ring->hdr[s_] = make_uint2((step_), (nu_) | ((need_) << 16) | ((ls_) << 24)); \
+  } while (0)
+  // (A window in which fewer of the needle's trigrams occur AT ALL than a candidate needs, left out by the publishing
+  // wave -- two ballots over the table it holds -- measured in round 3: 255.5 vs 252.9 ms, 1 % slower: at Geonames
+  // scale the bound hardly ever bites.)
+  // Unit k of a step belongs to worker k mod 15 and is that wave's (k / 15)-th: a slot is laid out wave by wave, so
+  // that ONE read -- lane j the wave's j-th unit -- hands a worker all its descriptors of a step.
+#define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + min(lane, ring_rows - 1)])
+  // LEFT OUT of the count (round 4; the MaxScore argument of wsweep_kernel, inside the needle-major step): once the
+  // needle has a threshold -- `need_` matches to enter its top `keep` in this step's windows -- the l_max_ = need_ -
+  // nm_cmin LARGEST slices of at least nm_dense postings of a window need not be counted.  A reference with need_
+  // matches has at least need_ - L of them among the counted slices, so the scan finds it with the bound lowered by
+  // L; what it finds goes to the step's pending list, and the manager settles its exact count from the left-out
+  // slices' bitmaps during the next step (PEND_SETTLE).  Lane t ranks its slice among the window's dense ones by size
+  // (one readlane per dense slice); the chosen ones note where their postings start (UnitRing::hot) and list no units.
+#define BLURRILY_LEAVE_OUT(hs_, h_, A_, B_, units_)                              \
+  do {                                                                           \
+    const uint32_t size_ = (B_) - (A_);                                          \
+    const bool dense_ = size_ >= A.nm_dense;                                     \
+    uint32_t bigger_ = 0;                                                        \
+    for (unsigned long long m_ = __ballot(dense_); m_; m_ &= m_ - 1) {           \
+      const uint32_t u_ = __builtin_ctzll(m_);                                   \
+      const uint32_t su_ = __builtin_amdgcn_readlane(size_, u_);                 \
+      bigger_ += (su_ > size_ || (su_ == size_ && u_ < lane)) ? 1u : 0u;         \
+    }                                                                            \
+    const bool skip_ = dense_ && bigger_ < l_max_;                               \
+    const unsigned long long sm_ = __ballot(skip_);                              \
+    if (skip_) {                                                                 \
+      ring->hot[hs_][h_][__popcll(sm_ & ((1ull << lane) - 1ull))] = (A_);        \
+      units_ = 0;                                                                \
+    }                                                                            \
+    ls_ |= uint32_t(__popcll(sm_)) << (4u * (h_));                               \
+  } while (0)
+  // the manager publishes the units of the table into ring slot s_: a lane's even-window units, then its odd-window
+  // units, dealt over the fifteen workers (k / 15 by multiplication: k < 512)
+#define BLURRILY_PRODUCE(s_, hs_, step_, A0, B0, A1, B1)                         \
+  do {                                                                           \
+    const unsigned long long thr_ = ctl->thr;                                    \
+    uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFu); \
+    uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
+    uint32_t ls_ = 0;                                                            \
+    const uint32_t l_max_ = (can_leave && thr_ != kKeyInf && need_ > A.nm_cmin) ? min(need_ - A.nm_cmin, kNmMaxLeftOut) : 0u; \
+    if (l_max_) {                                                                \
+      BLURRILY_LEAVE_OUT(hs_, 0u, A0, B0, units0_);                              \
+      if (kNib) BLURRILY_LEAVE_OUT(hs_, 1u, A1, B1, units1_);                    \
+    }                                                                            \
+    if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
+    const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
+    const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
+    if (total_ > ring_cap) {                   /* every wave walks the table: ALL slices, nothing left out */ \
+      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk, need_, 0u);                     \
+    } else {                                                                     \
+      uint2* const slot_ = ring_slot(ring, s_, ring_units);                      \
+      const uint32_t at0_ = incl_ - units0_ - units1_;                           \
+      uint32_t row_ = (at0_ * 34953u) >> 19;         /* at0_ / 15 */             \
+      uint32_t wv_ = at0_ - row_ * kWorkers;                                     \
+      for (uint32_t j_ = 0; j_ < units0_; ++j_) {                                \
+        slot_[wv_ * ring_rows + row_] = make_uint2(A0 + j_ * 512, B0);           \
+        if (++wv_ == kWorkers) { wv_ = 0; ++row_; }                              \
+      }                                                                          \
+      for (uint32_t j_ = 0; j_ < units1_; ++j_) {                                \
+        slot_[wv_ * ring_rows + row_] = make_uint2((A1 + j_ * 512) | 1u, B1);    \
+        if (++wv_ == kWorkers) { wv_ = 0; ++row_; }                              \
+      }                                                                          \
+      /* the scan's bound, lowered by the most slices either window leaves out (a harvested counter is settled  \
+         exactly, so a bound that is too low for the other window costs a look, nothing else) */ \
+      const uint32_t lmost_ = max(ls_ & 15u, ls_ >> 4);                          \
+      BLURRILY_PUBLISH_HDR(s_, step_, total_, need_ - min(need_, lmost_), ls_);  \
+    }                                                                            \
+  } while (0)
+  // The units of ring slot s_ that belong to this worker (k = wid, wid + 15, ...): one unit's LDS
+  // atomics run while the next unit's load is in flight.  Which lanes loaded a group travels as a lane
+  // predicate -- an SGPR pair -- beside the unit in flight: no sentinels to fill idle lanes with, no liveness
+  // test before the atomics.  A unit's address is a scalar base (its first entry) plus the lane's 16 bytes:
+  // nothing per unit and lane but the load itself and one compare.  (Up to four of a wave's units loaded before
+  // the first is counted -- four loads in flight -- measured in round 3: 3.2 % SLOWER, 317.2 vs 307.4 ms.)
+#define BLURRILY_COUNT_UNITS(s_, n_, have_mine_)                                 \
+  do {                                                                           \
+    uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
+    uint32_t pend_h_ = 0;                                                        \
+    bool pend_live_ = false;                                                     \
+    uint2 dl_ = d_mine;                         /* (read a step ago, behind the count barrier) */ \
+    if (!(have_mine_)) dl_ = BLURRILY_MY_UNITS(s_);                              \
+    uint32_t j_ = 0, k_ = wid;                                                   \
+    if ((have_mine_) && pre_valid) {            /* the first unit is on its way since the scan before */ \
+      pend_ = pre_v; pend_h_ = pre_h; pend_live_ = pre_live;                     \
+      if (STATS(A) && wid < (n_))                                                \
+        st_ent += min(512u, __builtin_amdgcn_readlane(dl_.y, 0) - (__builtin_amdgcn_readlane(dl_.x, 0) & ~7u)); \
+      j_ = 1; k_ = wid + kWorkers;                                               \
+    }                                                                            \
+    pre_valid = false;                                                           \
+    for (; k_ < (n_); k_ += kWorkers, ++j_) {                                    \
+      const uint32_t x_ = __builtin_amdgcn_readlane(dl_.x, j_);                  \
+      const uint32_t y_ = __builtin_amdgcn_readlane(dl_.y, j_);                  \
+      const uint32_t x0_ = x_ & ~7u;                                             \
+      const bool live_ = lane8 < y_ - x0_;                                       \
+      uint4 v_ = pend_;                                                          \
+      if (live_) v_ = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x0_) + lane16); \
+      if (STATS(A)) st_ent += min(512u, y_ - x0_);                               \
+      if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);               \
+      pend_ = v_; pend_h_ = x_ & 1u; pend_live_ = live_;                         \
+    }                                                                            \
+    if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);                 \
+  } while (0)
+  // Behind a scan, in front of its barrier: the header of the next step and this wave's units of it have arrived
+  // (requested before the scan), the scan's registers are free -- the load of the wave's first unit of the next step
+  // goes out here and travels under the barrier and the glance at the pool: 288.0 -> 281.3 ms per 500 k needles.
+  // (The first TWO units loaded here and two loads kept in flight through the count: 313.0 ms, 11 % slower -- as
+  // with every other attempt at more loads in flight per wave, rounds 2 and 3.  Two units loaded here and ONE load
+  // in flight through the count: 330 ms while the compiler kept the second unit in scratch -- a value carried through
+  // the rare paths is spilled where it is loaded --, 289.4 vs 281.9 ms, 2.7 % slower, once it was declared dead there.
+  // A read-only kernel with this shape of access reaches 7.5 TB/s on the chip with one load in flight per wave
+  // (tools/micro/read_bw.hip): what the loads wait for is not more of them.  The units' loads marked
+  // non-temporal, global_load_dwordx4 ... nt: 330.6 ms, 17 % slower -- the postings of the Geonames-scale image
+  // are 253 MB, and the 256 MiB Infinity Cache holds most of them as long as they are allowed in.)
+#define BLURRILY_PRELOAD()                                                       \
+  do {                                                                           \
+    const uint32_t np_ = __builtin_amdgcn_readfirstlane(h_next.x);               \
+    const uint32_t nn_ = __builtin_amdgcn_readfirstlane(h_next.y) & 0xFFFFu;     \
+    pre_valid = np_ < v1 && nn_ != kRingWalk;                                    \
+    pre_live = false;                                                            \
+    if (pre_valid && wid < nn_) {                                                \
+      const uint32_t x_ = __builtin_amdgcn_readlane(d_mine.x, 0);                \
+      const uint32_t y_ = __builtin_amdgcn_readlane(d_mine.y, 0);                \
+      const uint32_t x0_ = x_ & ~7u;                                             \
+      pre_live = lane8 < y_ - x0_;                                               \
+      pre_h = x_ & 1u;                                                           \
+      if (pre_live) pre_v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x0_) + lane16); \
+    }                                                                            \
+  } while (0)
+  // more units than the ring lists: every wave -- the manager too -- walks the table of step p_ itself, all slices
+#define BLURRILY_COUNT_WALK(p_)                                                  \
+  do {                                                                           \
+    uint32_t fa0_, fb0_, fa1_, fb1_, k_ = 0;                                     \
+    const uint32_t wcode_ = lane < tc ? codes[lane] : 0u;                        \
+    BLURRILY_FETCH_TABLE(p_, wcode_, fa0_, fb0_, fa1_, fb1_);                    \
+    BLURRILY_FOR_SLOT_UNITS(kNW, fa0_, fb0_, wid, lane, k_,                      \
+                            { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 0u);   \
+                              if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
+    if (kNib)                                                                    \
+      BLURRILY_FOR_SLOT_UNITS(kNW, fa1_, fb1_, wid, lane, k_,                    \
+                              { bump_unit<CT>(cnt32, load_group(A.ent, c, sb), 1u); \
+                                if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8)); }); \
+  } while (0)
+  // The manager's turn of a step: it publishes the next visited step (whose table arrived a step ago), then chooses the
+  // step after the next (the threshold only changes behind select's barriers) and fetches its table, which travels
+  // during the barrier and the scan.
+#define BLURRILY_MANAGER_TURN(e_, s_)                                            \
+  do {                                                                           \
+    if (my_i < n_visit) {                                                        \
+      BLURRILY_PRODUCE((s_) ^ 1u, ((e_) + 1u) & 3u, BLURRILY_STEP_AT(my_i), ta, tb, ta1, tb1); \
+    } else if (lane == 0) {                                                      \
+      ring->hdr[(s_) ^ 1u] = make_uint2(v1, 0u);                                 \
+    }                                                                            \
+    PHASE_MARK(7);                                  /* next step's units published */ \
+    const uint32_t chosen_ = my_i;                                               \
+    BLURRILY_NEXT_VISIT(chosen_ + 1, my_i);                                      \
+    if (my_i != chosen_ + 1) PATH_FLAG(A, nd.q, kPathSkipped);                   \
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), mcode, ta, tb, ta1, tb1);       \
+  } while (0)
+  // The manager settles the PENDING candidates of ring slot slot_ (step pstep_, whose windows left ls_ slices out,
+  // noted in hot[hs_]): lane c takes candidate c -- in-window rank | parity << 16 | counted matches << 20 --, loads the
+  // word of every left-out slice's bitmap that holds the candidate's bit (up to eight loads in flight), adds the bits
+  // to the counted matches and admits the candidate to the pool, or not, like any harvested counter: into the pool's
+  // tail, which is the manager's alone (compact_pool moves it up), so that nothing a flooding scan does to the pool
+  // meanwhile can cost a settled candidate its place.  Done while the workers scan the next step.
+#define BLURRILY_PEND_SETTLE(slot_, hs_, pstep_, ls_)                            \
+  do {                                                                           \
+    const uint32_t np_ = min(__builtin_amdgcn_readfirstlane(ctl->pend_n[slot_]), pend_cap); \
+    if (np_) {                                                                   \
+      const uint32_t* const pl_ = pend_list(ring, slot_, ring_units);            \
+      for (uint32_t c_ = lane; c_ < np_; c_ += 64) {                             \
+        const uint32_t e_ = pl_[c_];                                             \
+        const uint32_t h_ = (e_ >> 16) & 1u, r16_ = e_ & 0xFFFFu;                \
+        const uint32_t L_ = ((ls_) >> (4u * h_)) & 15u;                          \
+        uint32_t w_[kNmMaxLeftOut];                                              \
+        _Pragma("unroll") for (uint32_t k_ = 0; k_ < kNmMaxLeftOut; ++k_) {      \
+          w_[k_] = 0;                                                            \
+          if (k_ < L_)                                                           \
+            w_[k_] = reinterpret_cast<const uint32_t*>(A.ent + (ring->hot[hs_][h_][k_] - kBitmapSlots))[r16_ >> 5]; \
+        }                                                                        \
+        uint32_t cnt_ = e_ >> 20;                                                \
+        _Pragma("unroll") for (uint32_t k_ = 0; k_ < kNmMaxLeftOut; ++k_) cnt_ += (w_[k_] >> (r16_ & 31u)) & 1u; \
+        if (STATS(A)) atomicAdd(&STATS(A)[kStatProbes], static_cast<unsigned long long>(L_)); \
+        const uint32_t rank_ = (pstep_) * kWPS * kWindowRanks + h_ * kWindowRanks + r16_; \
+        const unsigned long long key_ = (static_cast<unsigned long long>(tc - min(tc, cnt_)) << 32) | rank_; \
+        bool pass_ = key_ <= ctl->thr;                                           \
+        if (nd.has_floor) pass_ = pass_ && key_ > ctl->floor;                    \
+        if (pass_) {                                     /* (tombstones were looked at where it was harvested) */ \
+          const uint32_t at_ = atomicAdd(&ctl->adm_n, 1u);                       \
+          if (at_ < kAdmMax) pool[A.pool_cap - kAdmMax + at_] = key_;            \
+        }                                                                        \
+      }                                                                          \
+      if (lane == 0) ctl->pend_n[slot_] = 0;                                     \
+    }                                                                            \
+  } while (0)
+
+  const uint32_t lane8 = lane * 8, lane16 = lane * 16;
+  PHASE_DECL;
+  uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0;    // request counters (FindArgs::stats), wave-uniform
+  // ---- the manager's state: the needle's codes, the table it will publish next and its visit index, the step before
+  uint32_t mcode = 0, ta = 0, tb = 0, ta1 = 0, tb1 = 0, my_i = 0, p_prev = 0, ls_prev = 0;
+  // ---- a worker's: its units of the step about to start (lane j: its j-th), the first of them loaded ahead
+  uint2 d_mine = make_uint2(0, 0);
+  uint4 pre_v = make_uint4(0, 0, 0, 0);
+  uint32_t pre_h = 0;
+  bool pre_live = false, pre_valid = false;
+  (void)mcode; (void)ta; (void)tb; (void)ta1; (void)tb1; (void)my_i; (void)p_prev; (void)ls_prev;
+  (void)d_mine; (void)pre_v; (void)pre_h; (void)pre_live; (void)pre_valid; (void)lane8; (void)lane16; (void)pend_cap;
+  if (MANAGER) PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
+  if constexpr (MANAGER) {
+    __builtin_amdgcn_s_setprio(3);                              // the wave everybody's next step waits for
+    mcode = lane < tc ? codes[lane] : 0u;
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(0u), mcode, ta, tb, ta1, tb1);
+    BLURRILY_PRODUCE(0u, 0u, BLURRILY_STEP_AT(0u), ta, tb, ta1, tb1);
+    BLURRILY_NEXT_VISIT(1u, my_i);
+    BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), mcode, ta, tb, ta1, tb1);
+  }
+  // a threshold exists (it is set by compact_pool only, i.e. outside the hot loop below: re-read behind every exit)
+  bool have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
+  const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
+  __syncthreads();
+  uint2 h_next = ring->hdr[0];                                   // header of the step about to start
+  if constexpr (!MANAGER) d_mine = BLURRILY_MY_UNITS(0u);
+
+  // The sweep is a HOT LOOP of steps that need nothing special -- header, units (the manager: its turn), barrier,
+  // scan with the published bound (the manager: the step before's pending candidates), barrier, a glance at the pool --
+  // and is left for everything else (more units than the ring holds; no threshold yet: the cold start's bisection;
+  // the pool to be compacted, perhaps the step swept again), which is dealt with behind it before the loop is entered
+  // again.  Kept apart so that what only the rare paths need is not held in registers, nor worked out, step after step.
+  uint32_t e = 0;
+  for (;;) {
+    uint32_t left, s, p, n_units, hy_;
+    for (;; ++e) {
+      s = e & 1;
+      p = __builtin_amdgcn_readfirstlane(h_next.x);
+      hy_ = __builtin_amdgcn_readfirstlane(h_next.y);
+      n_units = hy_ & 0xFFFFu;
+      if (p >= v1) { left = kLeftDone; break; }                 // no step left
+      ++st_steps;
+      PHASE_MARK(0);                                            // loop overhead
+      if (n_units == kRingWalk) { left = kLeftWalk; break; }
+      if constexpr (MANAGER) {
+        BLURRILY_MANAGER_TURN(e, s);
+      } else {
+        BLURRILY_COUNT_UNITS(s, n_units, true);
+        PHASE_MARK(2);                                          // units counted
+      }
+      lds_barrier();                                            // counts and next descriptors visible
+      PHASE_MARK(3);                                            // barrier after count
+      // The next step's header and a worker's units of it were published before that barrier: requested now,
+      // they arrive under the scan instead of standing, one LDS round trip each (several hundred clocks behind the
+      // other workgroup's atomics), between the scan barrier and the first load of the next step.
+      h_next = ring->hdr[s ^ 1u];
+      if constexpr (!MANAGER) d_mine = BLURRILY_MY_UNITS(s ^ 1u);
+      if constexpr (MANAGER) {
+        if (can_leave) BLURRILY_PEND_SETTLE(s ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);   // while the workers scan
+        p_prev = p; ls_prev = n_units ? hy_ >> 24 : 0u;
+      }
+      if (n_units == 0) continue;                               // nothing of the needle in this step's windows
+      const uint32_t need = (hy_ >> 16) & 0xFFu;
+      if (need == 0) { left = kLeftSlowScan; break; }
+      if constexpr (!MANAGER) {
+        const uint32_t wbase = p * kWPS * kWindowRanks;
+        const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
+        scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, scan_pool_cap, &ctl->pool_n,
+                          &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr,
+                          hy_ >> 24, pend_list(ring, s, ring_units), &ctl->pend_n[s], pend_cap, uint32_t(NT - 64));
+        BLURRILY_PRELOAD();
+      }
+      PHASE_MARK(5);                                            // scan
+      lds_barrier();                                            // counters are zero again
+      PHASE_MARK(6);                                            // barrier after scan
+      // (Looking at the pool a count phase later -- the read requested here, used behind the next count barrier, a
+      // compaction then running with the next step counted and not yet scanned -- was built and measured in round 3:
+      // 2 % slower, 293.0 vs 287.2 ms per 500 k needles; the thresholds the headers carry are a step staler.)
+      const uint4 c_ = *reinterpret_cast<const uint4*>(&ctl->pool_n);          // pool_n, overflow, adm_n, (q)
+      const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x) + __builtin_amdgcn_readfirstlane(c_.z);
+      const uint32_t ov_ = __builtin_amdgcn_readfirstlane(c_.y);
+      if (ov_ != 0 || pn_ > sel_at || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
+    }
+    // ---- behind the hot loop: pending candidates first -- the manager's business, all waves wait ----------------
+    // Left in front of a count barrier: the step before's have not been looked at yet.  Left behind a scan with the
+    // pool or the step's own pending list overflowed: the step is swept again with every slice counted, its pending
+    // candidates would come twice and are dropped; not overflowed: they are settled behind the compaction below, which
+    // makes room in the pool's tail first.
+    const bool own_pending = can_leave && left == kLeftSelect && ctl->overflow == 0;   // (uniform: written behind barriers only)
+    if (can_leave) {
+      if constexpr (MANAGER) {
+        if (left == kLeftDone || left == kLeftWalk) BLURRILY_PEND_SETTLE((e & 1u) ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);
+        if (left == kLeftSelect && !own_pending && lane == 0) ctl->pend_n[s] = 0;
+        p_prev = p; ls_prev = 0;
+      }
+      __syncthreads();
+    }
+    if (left == kLeftDone) break;
+    // ---- the rare paths of step p ----------------------------------------------------------------
+    pre_valid = false;                                          // (a unit loaded ahead is dropped)
+    const uint32_t wbase = p * kWPS * kWindowRanks;
+    const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
+    if (left == kLeftWalk) {
+      if (MANAGER) PATH_FLAG(A, nd.q, kPathRingOverflow);
+      ++st_walk;
+      BLURRILY_COUNT_WALK(p);
+      if constexpr (MANAGER) BLURRILY_MANAGER_TURN(e, s);
+      __syncthreads();
+    }
+    // kLeftSelect: the step is scanned, select_after_scan finds the pool as the hot loop saw it; else: scan first
+    bool scanned = left == kLeftSelect;
+    for (;;) {
+      if (!scanned) {
+        scan_window<CT, NT>(A, nd, cnt128, pool, ctl, wbase, wlen, scan_pool_cap);
+        __syncthreads();
+      }
+      scanned = false;
+      if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q, scan_pool_cap)) break;
+      ++st_redo;                                                // pool overflow: sweep step p again -- every slice of it
+      if (n_units == kRingWalk || (hy_ >> 24) != 0) BLURRILY_COUNT_WALK(p);   // (the ring lists no units of left-out slices)
+      else if constexpr (!MANAGER) BLURRILY_COUNT_UNITS(s, n_units, false);
+      __syncthreads();
+    }
+    if (own_pending) {
+      if constexpr (MANAGER) BLURRILY_PEND_SETTLE(s, e & 3u, p, hy_ >> 24);
+      __syncthreads();
+    }
+    have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
+    ++e;
+    h_next = ring->hdr[e & 1];                                  // (published behind step p's count barrier)
+    if constexpr (!MANAGER) d_mine = BLURRILY_MY_UNITS(e & 1);
+  }
+  PHASE_FLUSH(A);
+  if (STATS(A) && lane == 0) {
+    atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
+    if (wid == 0) {
+      atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
+      atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
+      atomicAdd(&STATS(A)[kStatUnits], static_cast<unsigned long long>(st_walk));   // (needle-major: steps that walked the table)
+    }
+  }
+  (void)st_walk;
+  if constexpr (MANAGER) __builtin_amdgcn_s_setprio(0);
+  __syncthreads();                                              // ring and ctl quiet before the needle ends
+#undef BLURRILY_PEND_SETTLE
+#undef BLURRILY_MANAGER_TURN
+#undef BLURRILY_COUNT_WALK
+#undef BLURRILY_COUNT_UNITS
+#undef BLURRILY_PRELOAD
+#undef BLURRILY_PRODUCE
+#undef BLURRILY_LEAVE_OUT
+#undef BLURRILY_MY_UNITS
+#undef BLURRILY_PUBLISH_HDR
+#undef BLURRILY_FETCH_TABLE
+#undef BLURRILY_NEXT_VISIT
+#undef BLURRILY_WMT_AT
+#undef BLURRILY_STEP_AT
+}
+
+// ---- cooperative flavour (needles with <= 64 distinct trigrams: nearly all of them): the workgroup's last wave
+// manages the sweep, the others work through it (sweep_role)
+template <typename CT, int NT>
+__device__ __forceinline__ void sweep_coop(const FindArgs& A, const Needle& nd, const uint16_t* codes, uint32_t* cnt32,
+                                           unsigned long long* pool, Control* ctl, UnitRing* ring, const uint8_t* wmt,
+                                           const uint32_t w0, const uint32_t w1, const uint32_t ws) {
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == NT / 64 - 1)
+    sweep_role<CT, NT, true>(A, nd, codes, cnt32, pool, ctl, ring, wmt, w0, w1, ws);
+  else
+    sweep_role<CT, NT, false>(A, nd, codes, cnt32, pool, ctl, ring, wmt, w0, w1, ws);
+}
+
 // RANGED = latency mode (a needle's windows cut into ranges); a separate instantiation so the
 // throughput kernel does not carry the extra live registers.  SHORT = the launch owns only
 // needles with <= 64 distinct trigrams (one table slot per lane, which frees the registers for a
 // fourth unit in flight); 65..127 follow in a launch over the tokeniser's mid list.
 // Residency is set by LDS: two workgroups per CU with byte counters, one with 16-bit counters;
 // the second launch bound (waves per SIMD) asks the register allocator for exactly that.
-template <typename CT, int NT, bool RANGED, bool SHORT>
+// LEAVE (SHORT launches only) = the sweep may leave dense slices out of a step's count (sweep_coop: a manager wave
+// and fifteen workers); without it the round-3 sweep, every wave doing everything (sweep_coop_plain).
+template <typename CT, int NT, bool RANGED, bool SHORT, bool LEAVE>
 __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void find_kernel(const FindArgs A) {
   // The counters are a static array: their LDS address is a compile-time constant, so the
   // per-posting ds_add needs no base add.  Dynamic LDS behind them: candidate pool | slice table
@@ -1664,7 +2013,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
 
     if (tid == 0) {
       ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf;
-      ctl->pend_n[0] = 0; ctl->pend_n[1] = 0;
+      ctl->adm_n = 0; ctl->pend_n[0] = 0; ctl->pend_n[1] = 0;
       if (nd.has_floor) ctl->floor = A.floor[q];
     }
     __syncthreads();
@@ -1684,10 +2033,17 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
          length: about half the windows at Geonames scale) -- a counter there cannot exceed 15 whatever \
          the needle.  The byte-counter part goes first: it holds the needle's own length class. */      \
       const uint32_t nib_end = nd.T <= 15 ? sb : min(sb, max(sa, A.nib_windows));                       \
-      if (nib_end < sb)                                                                                 \
-        sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, nib_end, sb, max(st, nib_end));        \
-      if (sa < nib_end)                                                                                 \
-        sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, sa, nib_end, min(st, nib_end - 1));   \
+      if constexpr (LEAVE) {                                                                            \
+        if (nib_end < sb)                                                                               \
+          sweep_coop<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, nib_end, sb, max(st, nib_end));      \
+        if (sa < nib_end)                                                                               \
+          sweep_coop<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, sa, nib_end, min(st, nib_end - 1)); \
+      } else {                                                                                          \
+        if (nib_end < sb)                                                                               \
+          sweep_coop_plain<CT, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, nib_end, sb, max(st, nib_end));      \
+        if (sa < nib_end)                                                                               \
+          sweep_coop_plain<Nib, NT>(A, nd, codes, cnt32, pool, ctl, ring, wmt, sa, nib_end, min(st, nib_end - 1)); \
+      }                                                                                                 \
     } else if constexpr (sizeof(CT) == 1) {      /* byte counters: T <= 127 by construction */          \
       sweep_pipelined<CT, NT>(A, nd, codes, cnt32, pool, ctl, sa, sb, st);                              \
     } else {                                                                                            \
@@ -1715,7 +2071,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
         }
         BLURRILY_SWEEP(sw_a, sw_b, sw_st);
         if (pass == 0) {
-          compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+          compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, SHORT && LEAVE && coop_can_leave(A) ? A.pool_cap - kAdmMax : A.pool_cap);
           if (tid == 0) ctl->pool_n = 0;
           __syncthreads();
         }
@@ -1728,7 +2084,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     PHASE_NEEDLE(11);
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
-    compact_pool<NT>(pool, ctl, A.pool_cap, A.keep);
+    compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, SHORT && LEAVE && coop_can_leave(A) ? A.pool_cap - kAdmMax : A.pool_cap);
     __builtin_amdgcn_s_setprio(kSerialPrio);
     const uint32_t nres = ctl->pool_n;
     if (RANGED) {
@@ -1779,7 +2135,7 @@ __global__ __launch_bounds__(NT) void merge_parts_kernel(const FindArgs A) {
   const uint32_t tid = threadIdx.x;
   const uint32_t item = blockIdx.x, R = A.ranges;
   const uint32_t q = A.work_list ? A.work_list[item] : item;
-  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; }
+  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; }
   __syncthreads();
   for (uint32_t r = 0; r < R; ++r) {
     const uint32_t slot = item * R + r;
@@ -2230,7 +2586,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
   const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
   const uint32_t wmt = A.win_max_tri[w];
   const uint32_t keep = A.keep;
-  const uint32_t* soff = A.slice_off + size_t(w) * kNumCodes;
+  const uint2* soff = A.slice_se + size_t(w) * kNumCodes;
 
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   // request counters (FindArgs::stats), per wave
@@ -2283,9 +2639,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
   do {                                                                                    \
     nx_ta = nx_tb = 0; nx_bm = kNoBitmap;                                                 \
     if ((ti_) < n_tasks && lane < (s_task_meta[ti_] & 0xFFu)) {                           \
-      const uint32_t raw_ = soff[nx_code];                                                \
-      nx_tb = soff[nx_code + 1]; nx_ta = postings_start(raw_, nx_tb, A.dense_min8);        \
-      nx_bm = nx_ta != raw_ ? nx_ta : kNoBitmap;       /* a dense slice: its bitmap sits in front of its postings */ \
+      const uint2 se_ = soff[nx_code];                                                    \
+      nx_ta = se_.x; nx_tb = se_.y;                                                       \
+      nx_bm = nx_tb - nx_ta >= A.dense_min8 ? nx_ta : kNoBitmap;   /* a dense slice: its bitmap sits in front of its postings */ \
     }                                                                                     \
   } while (0)
     // What a task's owner publishes for one pass over the window: which dense slices are left out (the L largest,
@@ -2628,7 +2984,7 @@ __global__ void finalize_rows_kernel(const FindArgs A, const uint32_t n) {
 size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
   static_assert(sizeof(Control) <= 64, "the unit ring sits 64 bytes behind the control block");
   return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 2 * size_t(ring_units_for(pool_cap)) * 8 +
-         2 * kPendMax * 4 + 16;
+         (pool_cap <= 512 ? 2 * kPendMax * 4 : 0) + 16;   // (pending lists: only where slices can be left out)
 }
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
   return size_t(kWindowSize) * counter_bytes + find_dynamic_lds_bytes(pool_cap);
@@ -2691,15 +3047,15 @@ static bool first_launch_on_this_device(std::atomic<uint64_t>& seen) {
   return (seen.fetch_or(bit) & bit) == 0;
 }
 
-template <typename CT, int NT, bool RANGED, bool SHORT>
+template <typename CT, int NT, bool RANGED, bool SHORT, bool LEAVE = false>
 static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   const size_t lds = find_dynamic_lds_bytes(a.pool_cap);
   static std::atomic<uint64_t> attr_done{0};
   if (first_launch_on_this_device(attr_done))
-    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT>),
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT, LEAVE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024 - int(kWindowSize * sizeof(CT))));   // static counters
-  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT>), dim3(grid), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT, LEAVE>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2708,8 +3064,13 @@ template <typename CT, int NT>
 static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   if constexpr (sizeof(CT) == 1) {
     if (a.short_only) {
-      if (a.ranges > 1) return launch_find_tr<CT, NT, true, true>(a, grid, stream);
-      return launch_find_tr<CT, NT, false, true>(a, grid, stream);
+      // (slices can be left out of a step's count: a limit of at most 64 -- the 512-entry pool --, not phase 1 of the
+      // window-major sweep; sweep_role's coop_can_leave asks the same)
+      const bool leave = a.nm_cmin != 0 && a.pool_cap <= 512 && !a.own_only;
+      if (a.ranges > 1) return leave ? launch_find_tr<CT, NT, true, true, true>(a, grid, stream)
+                                     : launch_find_tr<CT, NT, true, true>(a, grid, stream);
+      return leave ? launch_find_tr<CT, NT, false, true, true>(a, grid, stream)
+                   : launch_find_tr<CT, NT, false, true>(a, grid, stream);
     }
   }
   if (a.ranges > 1) return launch_find_tr<CT, NT, true, false>(a, grid, stream);

@@ -230,3 +230,45 @@ def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
     assert r["peak"] == 8000.0 and r["achievable_peak"] == 6290.0 and r["read_ceiling"] == 7490.0
     assert abs(r["frac"] * r["peak"] - r["achieved"]) < 1e-6 * r["achieved"]
     assert abs(r["frac_of_read_ceiling"] * r["read_ceiling"] - r["achieved"]) < 1e-6 * r["achieved"]
+
+
+def _run_bench(args, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_fails_loudly_when_a_leg_fails():
+    """A bench line without its CPU baseline, or with a dead extra config, is not a result: the line is still
+    printed, carries the error, and the exit status is 1 (VERDICT r03 "weak" #6)."""
+    res, d = _run_bench(["--steps", "2", "--warmup", "1", "--scale", "0.02", "--cpu-budget", "1", "--latency-probes", "0",
+                         "--inject-failure", "words"])
+    assert res.returncode == 1, (res.returncode, res.stderr[-1500:])
+    assert d is not None and "injected failure" in d["extra_configs"]["words"]["cpu_baseline"]["error"]
+    # the legs that did not fail are whole, parity floor included (32 needles whatever the budget)
+    assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 32
+    for name in ("skewed", "geonames_x4", "geonames_miss"):
+        x = d["extra_configs"][name]
+        assert "error" not in x and x["parity_checked"] >= 32 and x["cpu_baseline"]["parity_mismatches"] == 0, (name, x)
+        assert x["roofline"]["counted_launch_rows_equal_timed"] is True and x["roofline"]["sweep"] == x["roofline"]["counted_sweep"]
+    res, d = _run_bench(["--steps", "2", "--warmup", "1", "--scale", "0.02", "--cpu-budget", "1", "--latency-probes", "0",
+                         "--no-extra", "--inject-failure", "geonames"])
+    assert res.returncode == 1 and "injected failure" in d["cpu_baseline"]["error"]
+
+
+def test_bench_in_process_over_two_logical_devices():
+    """`--gpus 2 --in-process`: one process, option "devices" 2 (with one GPU on the box both replicas live on it), the
+    two ranks' needles in one call.  Plumbing, not a measurement: the line's bookkeeping, and rows equal to the
+    reference's on the checked prefix."""
+    res, d = _run_bench(["--gpus", "2", "--in-process", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--cpu-budget", "1",
+                         "--latency-probes", "0"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["config"]["needles_per_gpu"] == 50000 and "in-process" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 50000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 32 and "extra_configs" not in d

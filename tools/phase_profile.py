@@ -30,6 +30,12 @@ def main():
     hay, off = W.geonames(n, max(1000, int(500000 * min(1.0, scale * 4))), 3)
     m = RawMap()
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    for key in ("nm_cmin", "nm_dense", "wsweep"):                 # e.g. NM_CMIN=0: nothing left out of the needle-major count
+        if os.environ.get(key.upper()):
+            try:
+                m.set_option(key, int(os.environ[key.upper()]))
+            except OSError:                                           # (a build from before round 4)
+                pass
     m.sync_device()
     info = m.device_info()
     lib = _native.lib()

@@ -18,6 +18,12 @@ m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
 m.set_option("ws_min_slice", int(os.environ.get("WS_MIN_SLICE", "0")))
 m.set_option("ws_static_slice", 0); m.set_option("ws_autotune", 0)
 m.set_option("wsweep", int(os.environ.get("WSWEEP", "1")))     # WSWEEP=0: the needle-major sweep
+for key in ("nm_cmin", "nm_dense"):                               # NM_CMIN=0: nothing left out of the needle-major count
+    if os.environ.get(key.upper()):
+        try:
+            m.set_option(key, int(os.environ[key.upper()]))
+        except OSError:                                           # (a build from before round 4)
+            pass
 m.sync_device()
 q, qo = W.queries(hay, off, nq, 3000)
 m.set_timing(True)
