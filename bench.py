@@ -358,7 +358,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     sum_nb, sum_rows = int(nb.sum()), int(gpu_counts.astype(np.int64).sum())
     algo_bytes = 8 * sum_nb + 8 * sum_T + 12 * sum_rows + 4 * n_q            # SURVEY.md 8(d), one launch
     k_ms = float(np.mean(kernel_ms))
-    sweeps = {0: "latency mode / long needles only", 1: "needle-major", 2: "window-major"}
+    sweeps = {0: "latency mode / long needles only", 1: "needle-major", 2: "window-major",
+              3: "needle-major, dense slices left out of the count"}
     sweep = sweeps[m.get_option("last_sweep")]                               # of the timed launches
     # one more launch, untimed, with the kernels' own request counters on: the physical bytes and the
     # LDS-atomic lanes of exactly this batch -- by the SAME sweep (a measured choice is kept while counting)
@@ -494,7 +495,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                                  "counted before the Infinity Cache); see bound_scope and extra_configs.geonames_x4",
                 "kernel_source_hash": kernel_source_hash(),
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
-                           else "find_kernel<uint8_t,1024>" + (" (slices left out, settled by bitmap)" if st["probes"] else "")),
+                           else "find_kernel<uint8_t,1024,false,true,true> (manager + workers; slices left out, settled by bitmap)"
+                           if sweep.startswith("needle-major, dense") else "find_kernel<uint8_t,1024,false,true,false>"),
                 "sweep": sweep, "counted_sweep": counted_sweep,
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,

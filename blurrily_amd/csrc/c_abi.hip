@@ -115,14 +115,16 @@ struct trigram_map_t {
   uint32_t    ws_cmin = 3;              // a left-out slice must leave at least this many counted matches
   uint32_t    nm_cmin = 3;              // the same for the needle-major sweep (0: it leaves nothing out)
   uint32_t    nm_dense = 4096;          // ... which leaves out slices of at least this many postings only
+  uint32_t    nm_min_windows = 256;     // ... and, where the choice is not measured, on images of at least this many windows
   uint32_t    ws_min_needles = 16384;   // smaller batches: needle-major
   bool        ws_autotune = true;       // measure the choice per class of batch on first use (run_find_on)
   uint32_t    ws_static_slice = 2200;   // the static rule's mean_hit_slice (autotune off): break-even of the skewed family
-  int         ws_choice[6] = {0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major
-  float       ws_tuned_ms[6][2] = {};   // what the measurement saw (needle-major, window-major)
-  int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2; 0: neither yet)
+  int         ws_choice[6] = {0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major,
+                                                   // 3 needle-major with slices left out
+  float       ws_tuned_ms[6][3] = {};   // what the measurement saw (needle-major, window-major, slices left out)
+  int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2 / 3; 0: none yet)
   size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
-  hipEvent_t  tune_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t  tune_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int         n_cus = 0;
   bool        timing = false;
   bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
@@ -315,7 +317,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   a.tomb = d_tomb;
   a.dense_min8 = ix.dense_min8;
   a.nm_dense = std::max((m->nm_dense + 7u) & ~7u, ix.dense_min8);
-  a.nm_cmin = m->nm_cmin;
+  a.nm_cmin = 0;                                     // (set per launch sequence: see "WHICH sweep" below)
   a.stats = m->collect_stats ? m->d_stats : nullptr;
   const bool cb = a.stats != nullptr;
   if (cb) {                                          // wave 0's phase clocks per workgroup (counted build only)
@@ -424,67 +426,82 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       }
       return 0;
     };
-    // WHICH sweep: an image can take the window-major one at all if it has bitmaps (IndexBuildOptions::
-    // wants_bitmaps: enough windows, mean_hit_slice at or above "ws_min_slice" -- below it the sweep lost on every
-    // haystack measured).  Above it no statistic of the image predicts the winner across kinds of haystack
-    // (tools/gate_probe.py, DESIGN.md section 5: at the same mean_hit_slice one family wins 1.4x where another
-    // loses 0.7x), so the choice is MEASURED: the first batch of a class -- limit up to / above 32, by batch size
-    // 16 384.. / 65 536.. / 262 144.. -- on an image runs both sweeps (they give the same rows; the call waits for
-    // them, once), and the faster one serves that class until the image is rebuilt or an option changes.  With
-    // "ws_autotune" 0 (or while request counters are collected) the static rule of the measured table applies.
-    bool use_ws = false;
+    // WHICH sweep serves the batch's short needles.  Three can: the needle-major sweep as it was through round 3
+    // (1: every posting of every needle trigram counted), the needle-major sweep that leaves the largest dense
+    // slices out of a step's count and settles candidates through bitmaps (3: "nm_cmin" > 0, limits up to 64), and
+    // the window-major sweep (2: an image whose mean_hit_slice reaches "ws_min_slice", batches from "ws_min_needles"
+    // on, limits up to 128).  No statistic of the image predicts the winner across kinds of haystack and of needles
+    // (at the same mean_hit_slice one family of haystacks wins 1.4x with the window-major sweep
+    // where another loses 0.7x; leaving slices out wins 14 % on a haystack four times Geonames scale, 3 % at
+    // Geonames scale, and LOSES 9 % there on needles without a close match), so the choice is MEASURED: the first
+    // batch of a class -- limit up to / above 32, by batch size 16 384.. / 65 536.. / 262 144.. -- on an image runs
+    // every sweep it can take (they give the same rows; that one call waits for them), the plain sweep twice -- the
+    // first run of all meets cold caches -- and the fastest serves the class until the image is rebuilt or an option
+    // changes; a sweep other than the plain one has to win by 3 % (window-major: 5 %, it pays a launch per window).
+    // With "ws_autotune" 0, for smaller batches, and while request counters are collected on an unmeasured class, the
+    // static rules apply: window-major by the measured table's mean_hit_slice rule, slices left out from 256 windows.
+    const uint32_t cmin_opt = m->nm_cmin;
+    const bool leave_possible = ranges <= 1 && cmin_opt != 0 && limit <= 64 && ix.n_bitmaps != 0;
     const bool ws_possible = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.n_bitmaps != 0 &&
                              m->build_opt.ws_can_run(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
-    if (ws_possible) {
+    auto run_sweep = [&](int which) -> int {           // 1 plain, 2 window-major, 3 slices left out
+      a.nm_cmin = which == 3 ? cmin_opt : 0u;
+      return which == 2 ? run_ws() : run_nm();
+    };
+    int choice = 1;
+    a.nm_cmin = 0;                                     // (latency mode and the long-needle launches leave nothing out)
+    if (ranges <= 1) {
       // (a chunk of a host-buffer batch belongs to the class of the WHOLE batch: class_hint)
       const size_t n_cls = std::max(n, m->class_hint);
       const double slice_factor = (n_cls < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
-      const bool static_rule = ix.mean_hit_slice >= slice_factor * double(m->ws_static_slice);
+      const int static_choice = ws_possible && ix.mean_hit_slice >= slice_factor * double(m->ws_static_slice) ? 2
+                                : leave_possible && ix.n_windows >= m->nm_min_windows ? 3 : 1;
       const int cls = (limit > 32 ? 3 : 0) + (n_cls < 65536 ? 0 : n_cls < 262144 ? 1 : 2);
-      if (!m->ws_autotune || &ix != &m->dev) {
-        use_ws = static_rule;
-      } else if (m->ws_choice[cls] != 0) {
-        use_ws = m->ws_choice[cls] == 2;
+      const bool tunable = m->ws_autotune && is_base && n_cls >= 16384 && (leave_possible || ws_possible);
+      if (!tunable) {
+        choice = static_choice;
+      } else if (m->ws_choice[cls] != 0 && (m->ws_choice[cls] != 2 || ws_possible) && (m->ws_choice[cls] != 3 || leave_possible)) {
+        choice = m->ws_choice[cls];
       } else if (cb) {
-        use_ws = static_rule;                          // (counters must describe ONE sweep: an unmeasured class is not measured here)
+        choice = static_choice;                        // (counters must describe ONE sweep: an unmeasured class is not measured here)
       } else {
-        // Measure this class, once: needle-major, window-major, needle-major AGAIN -- the first run of the three
-        // meets cold caches (the image's postings are about the size of the Infinity Cache) and pays whatever a
-        // first launch pays, so the needle-major figure is the better of its two runs; the window-major sweep is
-        // preferred only when it wins by 5 % (it pays one launch per window, and a tie is no reason for that).
         if (!m->tune_ev[0]) {
-          hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+          hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
           for (auto& e : ev)
             if (hipEventCreate(&e) != hipSuccess) {
               for (auto& d : ev) if (d) (void)hipEventDestroy(d);
               errno = EIO;
               return -1;
             }
-          for (int i = 0; i < 4; ++i) m->tune_ev[i] = ev[i];
+          for (int i = 0; i < 5; ++i) m->tune_ev[i] = ev[i];
         }
+        const int order[4] = {1, leave_possible ? 3 : 0, ws_possible ? 2 : 0, 1};
+        float ms_of[4] = {0.f, 0.f, 0.f, 0.f};         // by sweep: [1] plain (the better of its two runs), [2], [3]
         BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[0], stream));
-        if (run_nm() < 0) return -1;
-        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[1], stream));
-        if (run_ws() < 0) return -1;
-        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[2], stream));
-        if (run_nm() < 0) return -1;
-        BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[3], stream));
-        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[3]));
-        float nm_ms = 0.f, ws_ms = 0.f, nm2_ms = 0.f;
-        BLURRILY_HIP_TRY(hipEventElapsedTime(&nm_ms, m->tune_ev[0], m->tune_ev[1]));
-        BLURRILY_HIP_TRY(hipEventElapsedTime(&ws_ms, m->tune_ev[1], m->tune_ev[2]));
-        BLURRILY_HIP_TRY(hipEventElapsedTime(&nm2_ms, m->tune_ev[2], m->tune_ev[3]));
-        nm_ms = std::min(nm_ms, nm2_ms);
-        m->ws_choice[cls] = ws_ms < 0.95f * nm_ms ? 2 : 1;
-        m->ws_tuned_ms[cls][0] = nm_ms; m->ws_tuned_ms[cls][1] = ws_ms;
-        m->last_sweep = 1;                             // (the rows in place are the needle-major run's; both give the same)
-        (void)is_base;
+        for (int k = 0; k < 4; ++k) {
+          if (order[k] && run_sweep(order[k]) < 0) return -1;
+          BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[k + 1], stream));
+        }
+        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[4]));
+        for (int k = 0; k < 4; ++k) {
+          if (!order[k]) continue;
+          float ms = 0.f;
+          BLURRILY_HIP_TRY(hipEventElapsedTime(&ms, m->tune_ev[k], m->tune_ev[k + 1]));
+          ms_of[order[k]] = ms_of[order[k]] == 0.f ? ms : std::min(ms_of[order[k]], ms);
+        }
+        choice = 1;
+        float best = ms_of[1];
+        if (leave_possible && ms_of[3] < 0.97f * ms_of[1]) { choice = 3; best = ms_of[3]; }
+        if (ws_possible && ms_of[2] < 0.95f * ms_of[1] && ms_of[2] < best) choice = 2;
+        m->ws_choice[cls] = choice;
+        m->ws_tuned_ms[cls][0] = ms_of[1]; m->ws_tuned_ms[cls][1] = ms_of[2]; m->ws_tuned_ms[cls][2] = ms_of[3];
+        m->last_sweep = 1;                             // (the rows in place are the plain run's; all give the same)
+        a.nm_cmin = 0;
         goto short_needles_done;
       }
-    }
-    if (ranges <= 1) {
-      if ((use_ws ? run_ws() : run_nm()) < 0) return -1;
-      if (is_base) m->last_sweep = use_ws ? 2 : 1;
+      if (run_sweep(choice) < 0) return -1;
+      if (is_base) m->last_sweep = choice;
+      a.nm_cmin = 0;
     }
   short_needles_done:
     // longer needles: 16-bit counters, one workgroup per CU, 256 rows per pass
@@ -612,6 +629,7 @@ int ensure_replicas(trigram_map m) {
     // options and measured choices follow the primary's
     s->build_opt = m->build_opt; s->ws_cmin = m->ws_cmin; s->nm_cmin = m->nm_cmin; s->nm_dense = m->nm_dense;
     s->ws_min_needles = m->ws_min_needles; s->ws_autotune = m->ws_autotune; s->ws_static_slice = m->ws_static_slice;
+    s->nm_min_windows = m->nm_min_windows;
     for (int c = 0; c < 6; ++c) if (m->ws_choice[c]) s->ws_choice[c] = m->ws_choice[c];
     s->n_cus = 0;
     if (r.base_builds != m->base_builds || s->dev.device < 0) {
@@ -1137,7 +1155,8 @@ constexpr OptionSlot kMapOptions[] = {
     {"wsweep", 0, 1}, {"ws_cmin", 1, 64}, {"ws_min_windows", 0, 1 << 20}, {"ws_min_needles", 0, 1ll << 32},
     {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}, {"host_chunk", 0, 1ll << 30},
     {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0},
-    {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64}};
+    {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64},
+    {"nm_min_windows", 0, 1 << 20}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1174,6 +1193,7 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 11: m->nm_dense = uint32_t(value); break;
     case 12: m->last_sweep = 0; return 0;                // (value 0 only; nothing to measure again)
     case 13: m->n_devices = uint32_t(value); return 0;   // (replicas are made, or dropped, by the next large batch)
+    case 14: m->nm_min_windows = uint32_t(value); break;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1198,7 +1218,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 7: *value = m->ws_autotune; return 0;
     case 8: *value = m->ws_static_slice; return 0;
     case 9: {                                            // what was measured so far: class c's choice in bits 2c+1:2c
-      long long v = 0;
+      long long v = 0;                                   // (1 needle-major, 2 window-major, 3 needle-major with slices left out)
       for (int c = 0; c < 6; ++c) v |= (long long)(m->ws_choice[c]) << (2 * c);
       *value = v;
       return 0;
@@ -1207,6 +1227,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 11: *value = m->nm_dense; return 0;
     case 12: *value = m->last_sweep; return 0;
     case 13: *value = m->n_devices; return 0;
+    case 14: *value = m->nm_min_windows; return 0;
     default: errno = EINVAL; return -1;
   }
 }

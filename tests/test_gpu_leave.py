@@ -1,0 +1,121 @@
+"""The needle-major sweep that LEAVES dense slices out of a step's count (find_kernels.hip: sweep_role -- a manager
+wave and fifteen workers; c_abi.hip: sweep 3) against the oracle, row for row.  Once a needle has a threshold, the
+largest slices of at least "nm_dense" postings of a window (at most need - "nm_cmin" of them, four at most) are not
+counted; a reference that could still reach the threshold on its best case waits in the step's pending list and is
+settled through the left-out slices' bitmaps by the manager during the next step (storage.c:545-573 is what it must
+still compute: every reference's match count, the best `limit` by matches, weight, reference).  By default the sweep is
+taken where a measurement or the static rule ("nm_min_windows" 256) says so; here it is forced onto haystacks the oracle
+answers in seconds: "ws_autotune" 0, "wsweep" 0, "nm_min_windows" 0, small "dense_min" / "nm_dense"."""
+import numpy as np
+import pytest
+
+import workloads as W
+from blurrily_amd import RawMap
+from blurrily_amd.map import _pack
+from helpers import Oracle
+
+pytestmark = pytest.mark.gpu
+LEFT_OUT = 1 << 21            # kPathNmLeftOut
+
+
+def _pair(hay, off, **opts):
+    n = len(off) - 1
+    m, o = RawMap(), Oracle()
+    for k, v in dict(ws_autotune=0, wsweep=0, nm_min_windows=0, **opts).items():
+        m.set_option(k, v)
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    o.put_many(hay, off)
+    return m, o
+
+
+def _check(m, o, packed, off, limit, expect_left_out=True):
+    m.set_stats(True)
+    rows, counts = m.find_batch_packed(packed, off, limit)
+    st, flags = m.find_stats(), m.find_path_flags(len(off) - 1)
+    m.set_stats(False)
+    assert m.get_option("last_sweep") == 3, m.get_option("last_sweep")
+    if expect_left_out:
+        assert st["probes"] > 0 and (flags & LEFT_OUT).any(), st
+    want = o.batch(packed, off, limit=limit)
+    assert np.array_equal(counts, want["counts"])
+    live = np.arange(limit)[None, :] < counts[:, None].astype(np.int64)
+    bad = np.nonzero((np.where(live[:, :, None], rows, 0) != np.where(live[:, :, None], want["rows"], 0)).any(axis=(1, 2)))[0]
+    if len(bad):
+        q = int(bad[0])
+        nd = bytes(packed[int(off[q]):int(off[q + 1])])
+        raise AssertionError((len(bad), q, nd, rows[q, :counts[q]].tolist(), want["rows"][q, :counts[q]].tolist()))
+    # ... and the timed build of the same kernels writes the same rows
+    rows_t, counts_t = m.find_batch_packed(packed, off, limit)
+    assert np.array_equal(counts_t, counts) and np.array_equal(np.where(live[:, :, None], rows_t, 0), np.where(live[:, :, None], rows, 0))
+    return flags
+
+
+def _mixed(hay, off, n_q, seed):
+    """Edited haystack strings plus the awkward ones: whole long strings, gibberish (rare trigrams: runs of empty
+    steps, no threshold for a long time), empty, one letter."""
+    q, qo = W.queries(hay, off, n_q, seed)
+    needles = W.unpack(q, qo)
+    rng = np.random.default_rng(seed)
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    for i in np.argsort(lens)[-300:]:
+        needles.append(bytes(hay[int(off[i]):int(off[i + 1])]))
+    for _ in range(300):
+        needles.append(bytes(rng.choice(list(b"qxzjkvw"), size=int(rng.integers(1, 9))).tolist()))
+    needles += [b"", b"a", b" ", b"zzzzzzzz", b"e", b"the"]
+    order = rng.permutation(len(needles))
+    return _pack([needles[i] for i in order])
+
+
+@pytest.mark.parametrize("limit,cmin,dense", [(10, 3, 512), (10, 1, 256), (10, 2, 1024), (1, 3, 256), (3, 2, 512), (64, 3, 256),
+                                              (33, 3, 512), (10, 5, 256)])
+def test_geonames_medium_all_rows_vs_oracle(limit, cmin, dense):
+    hay, off = W.geonames(700000, 90000, 51)                   # 11 windows
+    m, o = _pair(hay, off, dense_min=256, nm_cmin=cmin, nm_dense=dense)
+    q, qo = _mixed(hay, off, 9000, 52)
+    flags = _check(m, o, q, qo, limit)
+    assert (flags & LEFT_OUT).sum() > 1000
+    m.close()
+
+
+def test_hot_trigram_haystack_and_massive_ties():
+    """configs[4]'s kind of haystack: a few trigrams in half the strings, lengths that collide -- the left-out slices are
+    the hot ones, the pending lists and the pool's tail fill up (overflows: the step swept again, every slice counted)."""
+    hay, off = W.skewed(500000, 53)
+    m, o = _pair(hay, off, dense_min=512, nm_cmin=2, nm_dense=512)
+    q, qo = W.queries(hay, off, 6000, 54)
+    _check(m, o, q, qo, 10)
+    _check(m, o, q, qo, 64)
+    m.close()
+
+
+def test_single_words_small_windows_and_latency_mode_is_left_alone():
+    hay, off = W.words(200000, 55)                              # 4 windows
+    m, o = _pair(hay, off, dense_min=128, nm_cmin=2, nm_dense=128)
+    q, qo = W.queries(hay, off, 20000, 56)
+    _check(m, o, q, qo, 10)
+    # a handful of needles: latency mode (ranges), which leaves nothing out; a limit above 64 neither
+    q2, qo2 = W.queries(hay, off, 40, 57)
+    rows, counts = m.find_batch_packed(q2, qo2, 10)
+    assert m.get_option("last_sweep") == 0
+    want = o.batch(q2, qo2, limit=10)
+    assert np.array_equal(counts, want["counts"])
+    rows, counts = m.find_batch_packed(q, qo, 100)
+    assert m.get_option("last_sweep") == 1
+    m.close()
+
+
+def test_tombstones_and_pending_puts_under_the_leaving_sweep():
+    """Deletes since the image was built (tombstone bits: a pending candidate is looked up where it is harvested) and
+    puts since then (the delta image, merged in) -- storage.c:584-612, :398-473 semantics under this sweep."""
+    hay, off = W.geonames(400000, 60000, 58)
+    strings = W.unpack(hay, off)
+    m, o = _pair(hay, off, dense_min=256, nm_cmin=2, nm_dense=256)
+    q, qo = W.queries(hay, off, 5000, 59)
+    _check(m, o, q, qo, 10)
+    for ref in range(1, 30000, 7):
+        assert m.delete(ref) == o.delete(ref)
+    for k, s in enumerate(strings[:300]):
+        assert m.put(s + b" x", 900000 + k, 0) == o.put(s + b" x", 900000 + k, 0)
+    _check(m, o, q, qo, 10)
+    assert m.device_info()["base_builds"] == 1
+    m.close()
