@@ -124,7 +124,7 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def build_haystack(name, scale, static_choice=False):
+def build_haystack(name, scale, static_choice=False, force_sweep=0):
     import workloads as W
     from blurrily_amd import RawMap
     t0 = time.time()
@@ -132,8 +132,14 @@ def build_haystack(name, scale, static_choice=False):
     n = len(off) - 1
     t1 = time.time()
     m = RawMap()
-    if static_choice:
+    if static_choice or force_sweep:
         m.set_option("ws_autotune", 0)
+    if force_sweep == 1:                                # needle-major, nothing left out
+        m.set_option("wsweep", 0); m.set_option("nm_cmin", 0)
+    elif force_sweep == 2:                              # window-major
+        m.set_option("ws_min_slice", 0); m.set_option("ws_static_slice", 0)
+    elif force_sweep == 3:                              # needle-major, dense slices left out of the count
+        m.set_option("wsweep", 0); m.set_option("nm_min_windows", 0)
     entries = m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     t2 = time.time()
     m.sync_device()
@@ -252,7 +258,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
 
     spec = W.BENCH_WORKLOADS[name]
     limit = spec["limit"]
-    m, hay, hay_off, entries_resident = build_haystack(name, args.scale, getattr(args, 'static_choice', False))
+    m, hay, hay_off, entries_resident = build_haystack(name, args.scale, getattr(args, 'static_choice', False),
+                                                        getattr(args, 'force_sweep', 0))
     # --in-process: ONE process, the device image replicated behind the C ABI (option "devices"), the batch of all
     # the ranks of the torch.distributed run -- the same needles, shard for shard -- handed over in one call
     devices = args.gpus if getattr(args, "in_process", False) else 1
@@ -369,6 +376,12 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     st = m.find_stats()
     m.set_stats(False)
     counted_sweep = sweeps[m.get_option("last_sweep")]
+    # what the library's own measurement of this class of batch saw (its first batch ran every sweep it can take)
+    tuned = None
+    if m.get_option("tuned_class") >= 0:
+        tuned = {"class": m.get_option("tuned_class"), "needle_major_ms": m.get_option("tuned_nm_us") / 1e3,
+                 "window_major_ms": m.get_option("tuned_ws_us") / 1e3 or None,
+                 "slices_left_out_ms": m.get_option("tuned_leave_us") / 1e3 or None}
     stats_rows_equal = bool(np.array_equal(gpu_counts, block.counts.cpu().numpy().view(np.uint32)))
     out_bytes = 12 * sum_rows + 4 * n_q + 4 * n_q                              # rows + counts + nb_entries
     needle_bytes = int(qo[-1]) + 8 * (n_q + 1) + 2 * (int(qo[-1]) + n_q)       # needles, offsets, code scratch (w+r)
@@ -497,7 +510,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
                            else "find_kernel<uint8_t,1024,false,true,true> (manager + workers; slices left out, settled by bitmap)"
                            if sweep.startswith("needle-major, dense") else "find_kernel<uint8_t,1024,false,true,false>"),
-                "sweep": sweep, "counted_sweep": counted_sweep,
+                "sweep": sweep, "counted_sweep": counted_sweep, "sweep_measured": tuned,
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_gbs": algo_bytes / (k_ms * 1e-3) / 1e9,
@@ -563,6 +576,9 @@ def main():
                          "the N ranks' needles in one call; no torch.distributed")
     ap.add_argument("--inject-failure", default=None, metavar="WORKLOAD",
                     help="(tests) make that workload's cpu_baseline leg raise: the line must carry the error and the exit status be 1")
+    ap.add_argument("--force-sweep", type=int, default=0, choices=(0, 1, 2, 3),
+                    help="1 needle-major, 2 window-major, 3 needle-major with slices left out: that sweep whatever a "
+                         "measurement would say (PMC passes of the sweep a bench run chose: tools/collect_profiles.sh)")
     ap.add_argument("--static-choice", action="store_true",
                     help="the sweep by the static rule, not by measuring both on the first batch (PMC passes: "
                          "every find call of the run then launches the same kernels)")

@@ -122,6 +122,7 @@ struct trigram_map_t {
   int         ws_choice[6] = {0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major,
                                                    // 3 needle-major with slices left out
   float       ws_tuned_ms[6][3] = {};   // what the measurement saw (needle-major, window-major, slices left out)
+  int         last_tuned = -1;          // the class measured most recently ("tuned_*_us" report its figures)
   int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2 / 3; 0: none yet)
   size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
   hipEvent_t  tune_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -437,7 +438,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // batch of a class -- limit up to / above 32, by batch size 16 384.. / 65 536.. / 262 144.. -- on an image runs
     // every sweep it can take (they give the same rows; that one call waits for them), the plain sweep twice -- the
     // first run of all meets cold caches -- and the fastest serves the class until the image is rebuilt or an option
-    // changes; a sweep other than the plain one has to win by 3 % (window-major: 5 %, it pays a launch per window).
+    // changes; a sweep other than the plain one has to win by 1.5 % (window-major: 5 %, it pays a launch per window).
     // With "ws_autotune" 0, for smaller batches, and while request counters are collected on an unmeasured class, the
     // static rules apply: window-major by the measured table's mean_hit_slice rule, slices left out from 256 windows.
     const uint32_t cmin_opt = m->nm_cmin;
@@ -491,10 +492,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         }
         choice = 1;
         float best = ms_of[1];
-        if (leave_possible && ms_of[3] < 0.97f * ms_of[1]) { choice = 3; best = ms_of[3]; }
+        if (leave_possible && ms_of[3] < 0.985f * ms_of[1]) { choice = 3; best = ms_of[3]; }
         if (ws_possible && ms_of[2] < 0.95f * ms_of[1] && ms_of[2] < best) choice = 2;
         m->ws_choice[cls] = choice;
         m->ws_tuned_ms[cls][0] = ms_of[1]; m->ws_tuned_ms[cls][1] = ms_of[2]; m->ws_tuned_ms[cls][2] = ms_of[3];
+        m->last_tuned = cls;
         m->last_sweep = 1;                             // (the rows in place are the plain run's; all give the same)
         a.nm_cmin = 0;
         goto short_needles_done;
@@ -1143,6 +1145,37 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
   return 0;
 }
 
+size_t blurrily_storage_device_info_sized(trigram_map m, void* info, size_t info_size) {
+  blurrily_device_info_t full;
+  std::memset(&full, 0, sizeof full);
+  (void)blurrily_storage_device_info(m, &full);
+  std::memcpy(info, &full, std::min(info_size, sizeof full));
+  return sizeof full;
+}
+
+int blurrily_storage_tune(trigram_map m, const char* packed, const uint64_t* offsets, size_t n_given, size_t n,
+                          uint16_t limit) {
+  if (!packed || !offsets || n_given == 0 || n == 0) { errno = EINVAL; return -1; }
+  // n needles, the given ones over and over: one host-buffer batch in one piece, whose class is then measured by the
+  // find itself if it has not been (run_find_on); the rows are thrown away
+  std::vector<uint64_t> off(n + 1);
+  std::vector<char> buf;
+  off[0] = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t g = i % n_given;
+    buf.insert(buf.end(), packed + offsets[g], packed + offsets[g + 1]);
+    off[i + 1] = buf.size();
+  }
+  if (buf.empty()) buf.push_back(0);
+  std::vector<trigram_match_t> rows(n * size_t(limit) + 1);
+  std::vector<uint32_t> counts(n);
+  const uint32_t chunk = m->host_chunk;
+  m->host_chunk = 0;
+  const int rc = blurrily_storage_find_batch(m, buf.data(), off.data(), n, limit, rows.data(), counts.data());
+  m->host_chunk = chunk;
+  return rc;
+}
+
 void blurrily_storage_set_timing(trigram_map m, int enabled) { m->timing = enabled != 0; }
 
 void blurrily_storage_set_stats(trigram_map m, int enabled) { m->collect_stats = enabled != 0; }
@@ -1156,7 +1189,8 @@ constexpr OptionSlot kMapOptions[] = {
     {"ws_min_slice", 0, 1ll << 31}, {"dense_min", 64, 65536}, {"host_chunk", 0, 1ll << 30},
     {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0},
     {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64},
-    {"nm_min_windows", 0, 1 << 20}};
+    {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
+    {"tuned_leave_us", 0, 0}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1194,6 +1228,7 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 12: m->last_sweep = 0; return 0;                // (value 0 only; nothing to measure again)
     case 13: m->n_devices = uint32_t(value); return 0;   // (replicas are made, or dropped, by the next large batch)
     case 14: m->nm_min_windows = uint32_t(value); break;
+    case 15: case 16: case 17: case 18: return 0;        // (read-only: what the last measurement saw)
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1228,6 +1263,10 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 12: *value = m->last_sweep; return 0;
     case 13: *value = m->n_devices; return 0;
     case 14: *value = m->nm_min_windows; return 0;
+    case 15: *value = m->last_tuned; return 0;             // -1: nothing measured yet
+    case 16: case 17: case 18:                             // microseconds of the sweep in that measurement (0: it could not run)
+      *value = m->last_tuned < 0 ? 0 : (long long)(1000.0 * m->ws_tuned_ms[m->last_tuned][FIND_OPTION(kMapOptions, key) - 16]);
+      return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -229,6 +229,14 @@ class RawMap:
             _raise_errno()
         return out
 
+    def tune(self, packed, offsets, n, limit):
+        """Measure now which sweep serves batches of n needles at this limit (blurrily_storage_tune): the needles
+        given, repeated up to n, go through every sweep the class can take."""
+        self._check_open()
+        buf = np.frombuffer(packed, dtype=np.uint8) if not isinstance(packed, np.ndarray) else packed
+        if self._lib.blurrily_storage_tune(self._h, buf.ctypes.data, offsets.ctypes.data, len(offsets) - 1, n, limit) < 0:
+            _raise_errno()
+
     def set_option(self, key, value):
         """A tunable of this map (include/blurrily_storage.h: blurrily_storage_set_option)."""
         self._check_open()

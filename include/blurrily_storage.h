@@ -116,10 +116,22 @@ int blurrily_storage_find_batch(trigram_map haystack, const char* packed,
                                 trigram_match results, uint32_t* counts);
 
 /* Device-resident variant: every pointer is a device pointer on the map's GPU;
- * work is enqueued on `stream` (a hipStream_t; NULL = default stream) and NOT
- * synchronised.  d_nb_entries (optional, may be NULL) receives per query the
- * reference's nb_entries (storage.c:498-502), the unit of the
- * matched-entries/s metric. */
+ * work is enqueued on `stream` (a hipStream_t; NULL = default stream) and the
+ * call returns without waiting for it -- with these exceptions, each of which
+ * blocks the calling thread until the work enqueued so far on `stream` is done:
+ *   - the first call after a mutation builds / refreshes the device image
+ *     (as blurrily_storage_sync_device would; call that first to keep it out);
+ *   - the first call after a blurrily_storage_delete uploads the deleted ranks and
+ *     sets their tombstone bits (a synchronous copy and a stream synchronise);
+ *   - with "ws_autotune" 1 (the default), the FIRST batch of a class -- limit up
+ *     to / above 32 x 16 384.. / 65 536.. / 262 144.. needles -- on an image runs
+ *     every sweep that can serve it and waits for them once, to note the fastest
+ *     (blurrily_storage_tune does that ahead of time; "ws_autotune" 0 never does);
+ *   - blurrily_storage_set_timing(1) and blurrily_storage_set_stats(1).
+ * With "devices" > 1 the batch is sharded over the replicas; `stream` then waits
+ * (on the device, not the host) for every replica's rows.
+ * d_nb_entries (optional, may be NULL) receives per query the reference's
+ * nb_entries (storage.c:498-502), the unit of the matched-entries/s metric. */
 int blurrily_storage_find_batch_device(trigram_map haystack, const char* d_packed,
                                        size_t packed_bytes, /* == offsets[n] */
                                        const uint64_t* d_offsets, size_t n, uint16_t limit,
@@ -149,6 +161,16 @@ int blurrily_storage_find_batch_raw(trigram_map haystack, const char* packed, co
  * by the first find after a mutation).  0, or -1 with errno. */
 int blurrily_storage_sync_device(trigram_map haystack);
 
+/* Measure NOW which sweep serves batches of `n` needles at `limit` on this map's
+ * image (what the first such batch would otherwise do inside its find call): runs
+ * `n` needles sampled from the host-side needles given -- packed / offsets as for
+ * blurrily_storage_find_batch, at least one needle, repeated as needed -- through
+ * every sweep the class can take and notes the fastest.  Synchronous.  After it,
+ * blurrily_storage_find_batch_device on that class never waits for a measurement.
+ * 0, or -1 with errno. */
+int blurrily_storage_tune(trigram_map haystack, const char* packed, const uint64_t* offsets,
+                          size_t n_given, size_t n, uint16_t limit);
+
 /* Tokeniser (ext/blurrily/tokeniser.h:34, tokeniser.c:59-119): `output` needs
  * strlen(input)+1 slots; returns the number of distinct codes, ascending. */
 int blurrily_tokeniser_parse_string(const char* input, uint16_t* output);
@@ -176,6 +198,12 @@ typedef struct blurrily_device_info_t {
                                    reference: postings a needle can expect to leave out per window */
 } blurrily_device_info_t;
 int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* info);
+/* The same for a caller compiled against another version of this header: at most
+ * `info_size` bytes are written (pass sizeof(blurrily_device_info_t) as the caller
+ * knows it); returns the size of the structure as the LIBRARY knows it, so that a
+ * caller can tell which trailing fields it got.  The structure only ever grows at
+ * its end. */
+size_t blurrily_storage_device_info_sized(trigram_map haystack, void* info, size_t info_size);
 
 /* When non-zero, find_batch_device brackets its kernels with hipEvents on the
  * launch stream and synchronises to fill last_*_kernel_ms (bench/profiling). */
@@ -206,14 +234,27 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_min_windows"  (8)     fewest windows of an image it is taken on
  *   "ws_min_slice"    (1550)  least mean postings a needle trigram finds per window for the sweep to be possible on
  *                             an image at all (such an image carries bitmaps of its dense slices)
- *   "ws_autotune"     (1)     above that, which sweep serves a class of batches (limit up to / above 32; 16 384.. /
- *                             65 536.. / 262 144.. needles) is MEASURED: the first such batch on an image runs both
- *                             (same rows; that one call waits for them) and the faster one serves the class until the
- *                             image is rebuilt or an option changes.  0: the static rule below
+ *   "ws_autotune"     (1)     which sweep serves a class of batches (limit up to / above 32; 16 384.. / 65 536.. /
+ *                             262 144.. needles) is MEASURED: the first such batch on an image runs every sweep it can
+ *                             take -- needle-major, window-major, needle-major with dense slices left out of the count
+ *                             -- (same rows; that one call waits for them, see blurrily_storage_tune) and the fastest
+ *                             serves the class until the image is rebuilt or an option changes.  0: the static rules below
  *   "ws_static_slice" (2200)  the static rule: window-major iff mean postings per window >= this, x1.7 for batches
  *                             under 65 536 needles, x1.7 for limits above 32, x4 for both (measured table)
  *   "ws_choice"       get: what has been measured (class c in bits 2c+1:2c: 0 not yet, 1 needle-major,
- *                             2 window-major); set 0: forget it
+ *                             2 window-major, 3 needle-major with slices left out); set 0: forget it
+ *   "tuned_class", "tuned_nm_us", "tuned_ws_us", "tuned_leave_us"   get: the class measured most recently (-1: none)
+ *                             and what its three sweeps took, in microseconds (0: that sweep could not run)
+ *   "last_sweep"      get: which sweep the last large batch took (1 / 2 / 3 as above; 0: latency mode)
+ *   "nm_cmin"         (3)     the needle-major sweep may leave the largest dense slices of a (needle, window) out of
+ *                             the count -- at most need - nm_cmin of them, four at most -- and settle the candidates
+ *                             that leaves pending through the slices' bitmaps; 0: never.  Limits up to 64
+ *   "nm_dense"        (4096)  ... slices of at least this many postings only (not below "dense_min")
+ *   "nm_min_windows"  (256)   ... and, where the choice is not measured, on images of at least this many windows
+ *   "devices"         (1)     replicate the device image on the first n visible devices (replica k on device (primary
+ *                             + k) mod visible) and shard every batch of at least 1 024 x n needles contiguously over
+ *                             them: blurrily_storage_find_batch and _find_batch_device alike -- the rows land in the
+ *                             caller's buffers, the answer does not depend on n.  Replicas follow puts and deletes
  *   "ws_min_needles"  (16384) smallest batch it is taken for
  *   "ws_cmin"         (3)     counted matches a left-out slice must leave
  *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing

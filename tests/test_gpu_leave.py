@@ -119,3 +119,45 @@ def test_tombstones_and_pending_puts_under_the_leaving_sweep():
     _check(m, o, q, qo, 10)
     assert m.device_info()["base_builds"] == 1
     m.close()
+
+
+def test_tune_measures_a_class_ahead_of_time():
+    """blurrily_storage_tune: the measurement the first batch of a class would otherwise make inside its find call --
+    so that blurrily_storage_find_batch_device on that class never waits for one (include/blurrily_storage.h)."""
+    hay, off = W.geonames(600000, 80000, 61)
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(hay, off, np.arange(1, len(off), dtype=np.uint32))
+    o.put_many(hay, off)
+    m.sync_device()
+    assert m.get_option("tuned_class") == -1 and m.get_option("ws_choice") == 0
+    q, qo = W.queries(hay, off, 3000, 62)
+    m.tune(q, qo, 70000, 10)                                    # 3 000 needles given, 70 000 run: class 1
+    assert m.get_option("tuned_class") == 1
+    picked = (m.get_option("ws_choice") >> 2) & 3
+    assert picked in (1, 2, 3) and m.get_option("tuned_nm_us") > 0 and m.get_option("tuned_leave_us") > 0
+    q2, qo2 = W.queries(hay, off, 70000, 63)
+    rows, counts = m.find_batch_packed(q2, qo2, 10)
+    assert m.get_option("last_sweep") == picked and (m.get_option("ws_choice") >> 2) & 3 == picked
+    idx = np.arange(0, 70000, 40, dtype=np.uint32)
+    want = o.batch(q2, qo2, idx=idx, limit=10)
+    live = np.arange(10)[None, :] < want["counts"][:, None].astype(np.int64)
+    assert np.array_equal(counts[idx], want["counts"])
+    assert np.array_equal(np.where(live[:, :, None], rows[idx], 0), np.where(live[:, :, None], want["rows"], 0))
+    m.close()
+
+
+def test_device_info_for_a_caller_of_another_header_version():
+    """blurrily_storage_device_info_sized writes no more than the caller's structure holds and says how large the
+    library's is (the structure only grows at its end)."""
+    import ctypes as C
+    from blurrily_amd import _native
+    m = RawMap()
+    m.put(b"london", 1, 0)
+    m.find(b"london", 1)
+    lib = _native.lib()
+    buf = (C.c_ubyte * 96)(*([0xEE] * 96))
+    full = lib.blurrily_storage_device_info_sized(m.handle, buf, 16)
+    assert full == C.sizeof(_native.DeviceInfo)
+    assert bytes(buf[16:]) == b"\xEE" * 80                      # nothing behind the 16 bytes the caller declared
+    assert int.from_bytes(bytes(buf[4:8]), "little") == 1       # n_refs
+    m.close()

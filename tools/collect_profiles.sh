@@ -3,11 +3,12 @@
 # Produces under gpurun_out/<tag>/ everything profiles/ is refreshed from:
 #   bench.json / bench.log             python bench.py (configs[2] with cpu_baseline + extra_configs)
 #   stats/                             rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline --no-extra`
-#   stats_skewed/                      the same for --workload skewed (the window-major sweep's kernels)
+#   stats_skewed/, stats_x4/           the same for --workload skewed (the window-major sweep's kernels) and geonames_x4 (the
+#                                      needle-major sweep that leaves slices out: an image seven times the Infinity Cache)
 #   pmc_{fetch,write,tcc}_<workload>/  rocprofv3 --pmc passes, one counter group per run, per workload
 #   traffic.json                       tools/traffic_summary.py over those passes
 # (PROFILE_COMMIT=<short hash> in the environment stamps traffic.json: the GPU box has no .git)
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -17,12 +18,22 @@ python $root/bench.py > $out/bench.json 2> $out/bench.log
 #  so that the kernel's average duration in the summary is the timed steps' and the warm-up's)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra --latency-probes 0 > $out/stats_bench.json 2> $out/stats_bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline --latency-probes 0 > $out/stats_skewed.json 2> $out/stats_skewed.log
-for wl in geonames words skewed; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x4 -o bench -- python $root/bench.py --workload geonames_x4 --no-cpu-baseline --latency-probes 0 > $out/stats_x4.json 2> $out/stats_x4.log
+# the sweep the bench run above took for a workload (its measured choice): the PMC passes force the same one
+sweep_of() { python - "$out/bench.json" "$1" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); wl = sys.argv[2]
+r = (d if wl == "geonames" else d["extra_configs"][wl])["roofline"]["sweep"]
+print(3 if r.startswith("needle-major, dense") else 2 if r.startswith("window") else 1)
+PY
+}
+for wl in geonames words skewed geonames_x4 geonames_miss; do
+  fs=$(sweep_of $wl)
   for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
     name=${pass%%:*}; ctrs=${pass#*:}
     d=$out/pmc_${name}_$wl
     mkdir -p $d
-    rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $wl --steps 1 --warmup 0 --static-choice --no-cpu-baseline --latency-probes 0 > $d/bench.json 2> $d/bench.log
+    rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $wl --steps 1 --warmup 0 --force-sweep ${fs:-0} --no-cpu-baseline --latency-probes 0 > $d/bench.json 2> $d/bench.log
   done
 done
 python $root/tools/traffic_summary.py $out > $out/traffic.json

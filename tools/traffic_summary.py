@@ -51,7 +51,7 @@ def main():
            # the caller, PROFILE_COMMIT=$(git rev-parse --short HEAD) in the gpurun command line)
            "kernel_source_hash": kernel_source_hash(), "commit": os.environ.get("PROFILE_COMMIT")}
     detail = {}
-    for wl in ("geonames", "words", "skewed"):
+    for wl in ("geonames", "words", "skewed", "geonames_x4", "geonames_miss"):
         d = {}
         for sub in ("fetch", "write", "tcc"):
             t = totals(os.path.join(base, f"pmc_{sub}_{wl}"))
