@@ -327,6 +327,13 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     a.phase_clocks = m->d_phase;
     a.path_flags = static_cast<uint32_t*>(m->ws_flags.p);   // (sized and zeroed by run_find)
   }
+#ifdef BLURRILY_TRACE
+  if (!cb) {                                         // (trace build: time stamps of a few needles' steps, timed kernels)
+    if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
+    BLURRILY_HIP_TRY(hipMemsetAsync(m->d_phase, 0, kPhaseBytes, stream));
+    a.phase_clocks = m->d_phase;
+  }
+#endif
   // every launch gets its own zeroed queue word (scalars[2..63]); recycled in stream order
   uint32_t queue_slot = 2;
   auto next_queue = [&]() -> uint32_t* {

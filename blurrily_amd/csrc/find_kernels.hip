@@ -64,6 +64,27 @@
 #define BLURRILY_KERNELS_END
 #endif
 
+// (temporary, timing only -- results wrong: bounds of what a step's chain has to gain)
+#ifndef BLURRILY_X1
+#define BLURRILY_X1 0
+#endif
+#ifndef BLURRILY_X2
+#define BLURRILY_X2 0
+#endif
+#ifndef BLURRILY_X4
+#define BLURRILY_X4 0
+#endif
+
+// (temporary) trace build of the TIMED kernels: shader-clock stamps of the steps of needles [kTraceQ0, kTraceQ0 + 64),
+// wave 0 (role 0) and the manager wave (role 1), eight marks per step, 64 steps per needle
+#if defined(BLURRILY_TRACE) && !defined(BLURRILY_COUNTED)
+#define TRACE_MARK(A, q_, e_, role_, mark_) do { if ((A).phase_clocks && (q_) - 200000u < 64u && (e_) < 64u) { \
+    const unsigned long long t_ = clock64(); \
+    if ((threadIdx.x & 63u) == 0) (A).phase_clocks[(((((q_) - 200000u) * 64u + (e_)) * 2u + (role_)) * 8u) + (mark_)] = t_; } } while (0)
+#else
+#define TRACE_MARK(A, q_, e_, role_, mark_) do { } while (0)
+#endif
+
 namespace blurrily {
 BLURRILY_KERNELS_BEGIN
 
@@ -91,6 +112,10 @@ constexpr int      kSerialPrio     = 2;    // wave priority in a workgroup's ser
 #define PHASE_FLUSH(A) do { if (threadIdx.x == 0 && (A).phase_clocks) { \
     for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + i_], ph_acc[i_]); \
     atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + 8], ph_units); atomicAdd(&(A).phase_clocks[blockIdx.x * 16 + 9], ph_lanes); } } while (0)
+// sweep_role's manager wave (the workgroup's last): its phases go to row kPhaseManagerRow + blockIdx.x
+constexpr uint32_t kPhaseManagerRow = 4096;
+#define PHASE_FLUSH_MANAGER(A) do { if ((threadIdx.x & 63u) == 0 && (A).phase_clocks) { \
+    for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(A).phase_clocks[(kPhaseManagerRow + blockIdx.x) * 16 + i_], ph_acc[i_]); } } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_NEEDLE_DECL
@@ -98,6 +123,7 @@ constexpr int      kSerialPrio     = 2;    // wave priority in a workgroup's ser
 #define PHASE_MARK(i)
 #define PHASE_UNIT(v)
 #define PHASE_FLUSH(A)
+#define PHASE_FLUSH_MANAGER(A)
 #endif
 constexpr uint64_t kKeyInf    = ~0ull;
 constexpr uint32_t kPadPair   = uint32_t(kPadRank) | (uint32_t(kPadRank) << 16);   // two padding sentinels
@@ -1464,6 +1490,11 @@ __device__ void sweep_coop_plain(const FindArgs& A, const Needle& nd, const uint
 }
 
 
+// inclusive sums of a published slice table's units (sweep_role: BLURRILY_TAB), lane t: the units up to and with slice t
+__device__ __forceinline__ uint32_t tab_incl(const uint4 tb) {
+  return (tb.w & 0xFFFFu) + (tb.w >> 16) + ((((tb.z >> 16) >> 3) + 63u) >> 6);
+}
+
 // One needle's sweep as ONE of two roles (round 4).  Through round 3 every wave of the workgroup did everything: its
 // share of a step's units, its share of the scan -- and, by turns, the choosing of the next step, the fetching of
 // its slice table and the publishing of its units, so that every wave held the table's registers and the turns' code,
@@ -1486,14 +1517,18 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   constexpr bool kNib = std::is_same<CT, Nib>::value;
   constexpr uint32_t kWPS = kNib ? 2 : 1;
   constexpr uint32_t kNW = NT / 64, kWorkers = kNW - 1;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t tid = threadIdx.x;
+  // (the lane number taken HERE, opaquely: derived from threadIdx.x it is a kernel-lifetime value, and with it every
+  // address and mask computed from it -- hoisted to the kernel's entry for both roles and all four sweeps, spilled there
+  // and reloaded from scratch inside the hot loops, each reload a wait for every global load in flight)
+  uint32_t lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
   const uint32_t wid = MANAGER ? kWorkers : __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tc = nd.T;                                     // <= 64
   const uint32_t v0 = w0 / kWPS, v1 = (w1 + kWPS - 1) / kWPS, vs = ws / kWPS;   // steps [v0, v1), first one vs
   const uint32_t n_visit = v1 - v0;
   uint4* const cnt128 = reinterpret_cast<uint4*>(cnt32);
-  const uint32_t ring_units = ring_units_for(A.pool_cap), ring_rows = ring_units / kNW;   // rows: units of a wave
-  const uint32_t ring_cap = kWorkers * ring_rows;               // units a slot lists (the manager's rows stay empty)
+  const uint32_t ring_units = ring_units_for(A.pool_cap);      // (where the pending lists start behind the ring: pend_list)
   // Slices are left out of a step's count only where the candidates that leaves pending are sure of their place in the
   // pool: limits up to 64 (the 512-entry pool), its last kAdmMax slots theirs alone, a step's pending list no longer than
   // what those slots hold beside the keys a glance lets pass (select_at()); not in phase 1 of the window-major sweep.
@@ -1506,27 +1541,40 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   // downward from it, round the start: 292.7 ms, 16 % slower -- every window visited later lies BEHIND the threshold's
   // rank when the sweep goes upward, and needs one match more)
 #define BLURRILY_STEP_AT(i_) ((i_) < n_visit ? (vs + (i_) < v1 ? vs + (i_) : vs + (i_) - n_visit) : v1)
-  // most trigrams of the needle a reference of the step's window(s) can hold
-#define BLURRILY_WMT_AT(i_, out_)                                                \
+  // Which step comes next: the first visit index >= from_ whose windows can hold a candidate (n_visit: none) -- a window
+  // is stepped over when no reference of it has as many trigrams as a candidate needs (win_max_tri).  The manager keeps
+  // the bounds of 64 visits in a register (lane l: visit wm_base + l; reloaded every 64 visits) and the threshold in
+  // scalar registers (thr_c: it moves only in compact_pool, i.e. outside the hot loop), so that choosing is one compare
+  // and a ballot -- no LDS round trip, which behind the workers' atomics takes 500 to 1 000 clocks each (through the first
+  // version of this round two dependent ones per step looked at: the bound's byte, the threshold).
+#define BLURRILY_LOAD_WMT(base_)                                                 \
   do {                                                                           \
-    const uint32_t p_ = min(BLURRILY_STEP_AT(i_), v1 - 1) * kWPS;                \
-    if (wmt) {                       /* the workgroup's LDS copy (clamped to 255 >= tc): no global round trip */ \
-      out_ = wmt[p_];                                                            \
-      if (kNib && p_ + 1 < w1) out_ = max(out_, uint32_t(wmt[p_ + 1]));          \
-    } else {                                                                     \
-      out_ = A.win_max_tri[p_];                                                  \
-      if (kNib && p_ + 1 < w1) out_ = max(out_, A.win_max_tri[p_ + 1]);          \
+    const uint32_t i_ = (base_) + lane;                                          \
+    uint32_t m_ = 0;                                                             \
+    if (i_ < n_visit) {                                                          \
+      const uint32_t p_ = BLURRILY_STEP_AT(i_) * kWPS;                           \
+      if (wmt) {                     /* the workgroup's LDS copy (clamped to 255 >= tc) */ \
+        m_ = wmt[p_];                                                            \
+        if (kNib && p_ + 1 < w1) m_ = max(m_, uint32_t(wmt[p_ + 1]));            \
+      } else {                                                                   \
+        m_ = A.win_max_tri[p_];                                                  \
+        if (kNib && p_ + 1 < w1) m_ = max(m_, A.win_max_tri[p_ + 1]);            \
+      }                                                                          \
     }                                                                            \
+    wm_l = m_; wm_base = (base_);                                                \
   } while (0)
-  // first visit index >= from_ whose step can hold a candidate (n_visit: none)
 #define BLURRILY_NEXT_VISIT(from_, out_)                                         \
   do {                                                                           \
-    out_ = (from_);                                                              \
-    while (out_ < n_visit) {                                                     \
-      uint32_t m_;                                                               \
-      BLURRILY_WMT_AT(out_, m_);                                                 \
-      if (min(tc, m_) >= matches_needed(ctl->thr, tc, BLURRILY_STEP_AT(out_) * kWPS * kWindowRanks)) break; \
-      ++out_;                                                                    \
+    uint32_t f_ = (from_);                                                       \
+    out_ = n_visit;                                                              \
+    while (f_ < n_visit) {                                                       \
+      const uint32_t b_ = f_ & ~63u;                                             \
+      if (b_ != wm_base) BLURRILY_LOAD_WMT(b_);                                  \
+      const uint32_t i_ = b_ + lane;                                             \
+      const uint32_t need_l_ = matches_needed(thr_c, tc, BLURRILY_STEP_AT(i_) * kWPS * kWindowRanks); \
+      const unsigned long long ok_ = __ballot(i_ < n_visit && min(tc, wm_l) >= need_l_) >> (f_ - b_); \
+      if (ok_) { out_ = f_ + uint32_t(__builtin_ctzll(ok_)); break; }           \
+      f_ = b_ + 64u;                                                             \
     }                                                                            \
   } while (0)
   // slice table of step p_ (lane t: the needle's trigram code_): (A0, B0) the (even) window, (A1, B1) the odd one
@@ -1558,9 +1606,26 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   // (A window in which fewer of the needle's trigrams occur AT ALL than a candidate needs, left out by the publishing
   // wave -- two ballots over the table it holds -- measured in round 3: 255.5 vs 252.9 ms, 1 % slower: at Geonames
   // scale the bound hardly ever bites.)
-  // Unit k of a step belongs to worker k mod 15 and is that wave's (k / 15)-th: a slot is laid out wave by wave, so
-  // that ONE read -- lane j the wave's j-th unit -- hands a worker all its descriptors of a step.
-#define BLURRILY_MY_UNITS(s_) (ring_slot(ring, s_, ring_units)[wid * ring_rows + min(lane, ring_rows - 1)])
+  // What the manager publishes of a step is its SLICE TABLE, one 16-byte store for the wave: lane t = the needle's
+  // trigram t -- .x / .y where the slice's postings start in `ent` (even / odd window of the step), .z their lengths in
+  // entries (16 bits each; 0: empty, or left out of the count), .w the units in front of the lane's (exclusive prefix
+  // sum, bits 15:0) and the units of its even slice (bits 23:16).  Unit k of the step belongs to worker k mod 15; a
+  // worker reads the table once per step (one 16-byte read, where it read its descriptors before) and finds unit k's
+  // slice with one compare and ballot over the inclusive sums (tab_incl), its bounds with four v_readlane.  (Through
+  // round-4's first version the manager listed every UNIT -- a store per unit from lanes looping over their slices,
+  // queued behind the workers' atomics: 4 300 clocks per step, the wave the count barrier waited for in nine steps of ten.)
+#define BLURRILY_TAB(s_) (reinterpret_cast<uint4*>(ring + 1) + (s_) * 64u)
+  // scalar bounds of the step's unit k_ from the table in tb_ / its inclusive sums incl_
+#define BLURRILY_UNIT_OF(tb_, incl_, k_, start_, end_, half_)                    \
+  do {                                                                           \
+    const uint32_t t_ = uint32_t(__builtin_ctzll(__ballot((incl_) > (k_)) | (1ull << 63))); \
+    const uint32_t a0_ = __builtin_amdgcn_readlane((tb_).x, t_), a1_ = __builtin_amdgcn_readlane((tb_).y, t_); \
+    const uint32_t z_ = __builtin_amdgcn_readlane((tb_).z, t_), w_ = __builtin_amdgcn_readlane((tb_).w, t_); \
+    const uint32_t ji_ = (k_) - (w_ & 0xFFFFu), u0_ = w_ >> 16;                  \
+    half_ = ji_ >= u0_ ? 1u : 0u;                                                \
+    start_ = half_ ? a1_ + (ji_ - u0_) * 512u : a0_ + ji_ * 512u;                \
+    end_ = half_ ? a1_ + (z_ >> 16) : a0_ + (z_ & 0xFFFFu);                      \
+  } while (0)
   // LEFT OUT of the count (round 4; the MaxScore argument of wsweep_kernel, inside the needle-major step): once the
   // needle has a threshold -- `need_` matches to enter its top `keep` in this step's windows -- the l_max_ = need_ -
   // nm_cmin LARGEST slices of at least nm_dense postings of a window need not be counted.  A reference with need_
@@ -1581,16 +1646,16 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     const bool skip_ = dense_ && bigger_ < l_max_;                               \
     const unsigned long long sm_ = __ballot(skip_);                              \
     if (skip_) {                                                                 \
-      ring->hot[hs_][h_][__popcll(sm_ & ((1ull << lane) - 1ull))] = (A_);        \
+      ring->hot[hs_][h_][__builtin_amdgcn_mbcnt_hi(uint32_t(sm_ >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(sm_), 0u))] = (A_); \
       units_ = 0;                                                                \
     }                                                                            \
     ls_ |= uint32_t(__popcll(sm_)) << (4u * (h_));                               \
   } while (0)
-  // the manager publishes the units of the table into ring slot s_: a lane's even-window units, then its odd-window
-  // units, dealt over the fifteen workers (k / 15 by multiplication: k < 512)
+  // the manager publishes the step's slice table into ring slot s_ (a lane's even-window units come first, then its
+  // odd-window units)
 #define BLURRILY_PRODUCE(s_, hs_, step_, A0, B0, A1, B1)                         \
   do {                                                                           \
-    const unsigned long long thr_ = ctl->thr;                                    \
+    const unsigned long long thr_ = thr_c;                                       \
     uint32_t need_ = min(matches_needed(thr_, tc, (step_) * kWPS * kWindowRanks), 0xFFu); \
     uint32_t units0_ = slice_units(A0, B0), units1_ = kNib ? slice_units(A1, B1) : 0u; \
     uint32_t ls_ = 0;                                                            \
@@ -1602,26 +1667,13 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
     const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
-    if (total_ > ring_cap) {                   /* every wave walks the table: ALL slices, nothing left out */ \
-      BLURRILY_PUBLISH_HDR(s_, step_, kRingWalk, need_, 0u);                     \
-    } else {                                                                     \
-      uint2* const slot_ = ring_slot(ring, s_, ring_units);                      \
-      const uint32_t at0_ = incl_ - units0_ - units1_;                           \
-      uint32_t row_ = (at0_ * 34953u) >> 19;         /* at0_ / 15 */             \
-      uint32_t wv_ = at0_ - row_ * kWorkers;                                     \
-      for (uint32_t j_ = 0; j_ < units0_; ++j_) {                                \
-        slot_[wv_ * ring_rows + row_] = make_uint2(A0 + j_ * 512, B0);           \
-        if (++wv_ == kWorkers) { wv_ = 0; ++row_; }                              \
-      }                                                                          \
-      for (uint32_t j_ = 0; j_ < units1_; ++j_) {                                \
-        slot_[wv_ * ring_rows + row_] = make_uint2((A1 + j_ * 512) | 1u, B1);    \
-        if (++wv_ == kWorkers) { wv_ = 0; ++row_; }                              \
-      }                                                                          \
-      /* the scan's bound, lowered by the most slices either window leaves out (a harvested counter is settled  \
-         exactly, so a bound that is too low for the other window costs a look, nothing else) */ \
-      const uint32_t lmost_ = max(ls_ & 15u, ls_ >> 4);                          \
-      BLURRILY_PUBLISH_HDR(s_, step_, total_, need_ - min(need_, lmost_), ls_);  \
-    }                                                                            \
+    /* (a slice left out of the count lists no units: its length is published as 0) */ \
+    const uint32_t len0_ = units0_ ? (B0) - (A0) : 0u, len1_ = units1_ ? (B1) - (A1) : 0u; \
+    BLURRILY_TAB(s_)[lane] = make_uint4((A0), (A1), len0_ | (len1_ << 16), (incl_ - units0_ - units1_) | (units0_ << 16)); \
+    /* the scan's bound, lowered by the most slices either window leaves out (a harvested counter is settled    \
+       exactly, so a bound that is too low for the other window costs a look, nothing else) */ \
+    const uint32_t lmost_ = max(ls_ & 15u, ls_ >> 4);                            \
+    BLURRILY_PUBLISH_HDR(s_, step_, total_, need_ - min(need_, lmost_), ls_);    \
   } while (0)
   // The units of ring slot s_ that belong to this worker (k = wid, wid + 15, ...): one unit's LDS
   // atomics run while the next unit's load is in flight.  Which lanes loaded a group travels as a lane
@@ -1634,26 +1686,30 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     uint4 pend_ = make_uint4(0, 0, 0, 0);                                        \
     uint32_t pend_h_ = 0;                                                        \
     bool pend_live_ = false;                                                     \
-    uint2 dl_ = d_mine;                         /* (read a step ago, behind the count barrier) */ \
-    if (!(have_mine_)) dl_ = BLURRILY_MY_UNITS(s_);                              \
-    uint32_t j_ = 0, k_ = wid;                                                   \
+    uint4 tl_ = tb_mine;                        /* (read a step ago, behind the count barrier) */ \
+    uint32_t il_ = incl_mine;                                                    \
+    if (!(have_mine_)) { tl_ = BLURRILY_TAB(s_)[lane]; il_ = tab_incl(tl_); }    \
+    uint32_t k_ = wid;                                                           \
     if ((have_mine_) && pre_valid) {            /* the first unit is on its way since the scan before */ \
       pend_ = pre_v; pend_h_ = pre_h; pend_live_ = pre_live;                     \
-      if (STATS(A) && wid < (n_))                                                \
-        st_ent += min(512u, __builtin_amdgcn_readlane(dl_.y, 0) - (__builtin_amdgcn_readlane(dl_.x, 0) & ~7u)); \
-      j_ = 1; k_ = wid + kWorkers;                                               \
+      if (STATS(A) && wid < (n_)) {                                              \
+        uint32_t x_, y_, h_;                                                     \
+        BLURRILY_UNIT_OF(tl_, il_, wid, x_, y_, h_);                             \
+        st_ent += min(512u, y_ - x_);                                            \
+      }                                                                          \
+      k_ = wid + kWorkers;                                                       \
     }                                                                            \
+    if (BLURRILY_X4 && (have_mine_) && pre_valid) k_ = (n_);                     \
     pre_valid = false;                                                           \
-    for (; k_ < (n_); k_ += kWorkers, ++j_) {                                    \
-      const uint32_t x_ = __builtin_amdgcn_readlane(dl_.x, j_);                  \
-      const uint32_t y_ = __builtin_amdgcn_readlane(dl_.y, j_);                  \
-      const uint32_t x0_ = x_ & ~7u;                                             \
-      const bool live_ = lane8 < y_ - x0_;                                       \
+    for (; k_ < (n_); k_ += kWorkers) {                                          \
+      uint32_t x_, y_, h_;                                                       \
+      BLURRILY_UNIT_OF(tl_, il_, k_, x_, y_, h_);                                \
+      const bool live_ = lane8 < y_ - x_;                                        \
       uint4 v_ = pend_;                                                          \
-      if (live_) v_ = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x0_) + lane16); \
-      if (STATS(A)) st_ent += min(512u, y_ - x0_);                               \
+      if (live_) v_ = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x_) + lane16); \
+      if (STATS(A)) st_ent += min(512u, y_ - x_);                                \
       if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);               \
-      pend_ = v_; pend_h_ = x_ & 1u; pend_live_ = live_;                         \
+      pend_ = v_; pend_h_ = h_; pend_live_ = live_;                              \
     }                                                                            \
     if (pend_live_) bump_unit_loaded<CT>(cnt32, pend_, pend_h_);                 \
   } while (0)
@@ -1672,18 +1728,18 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   do {                                                                           \
     const uint32_t np_ = __builtin_amdgcn_readfirstlane(h_next.x);               \
     const uint32_t nn_ = __builtin_amdgcn_readfirstlane(h_next.y) & 0xFFFFu;     \
-    pre_valid = np_ < v1 && nn_ != kRingWalk;                                    \
+    incl_mine = tab_incl(tb_mine);                                               \
+    pre_valid = np_ < v1;                                                        \
     pre_live = false;                                                            \
     if (pre_valid && wid < nn_) {                                                \
-      const uint32_t x_ = __builtin_amdgcn_readlane(d_mine.x, 0);                \
-      const uint32_t y_ = __builtin_amdgcn_readlane(d_mine.y, 0);                \
-      const uint32_t x0_ = x_ & ~7u;                                             \
-      pre_live = lane8 < y_ - x0_;                                               \
-      pre_h = x_ & 1u;                                                           \
-      if (pre_live) pre_v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x0_) + lane16); \
+      uint32_t x_, y_;                                                           \
+      BLURRILY_UNIT_OF(tb_mine, incl_mine, wid, x_, y_, pre_h);                  \
+      pre_live = lane8 < y_ - x_;                                                \
+      if (pre_live) pre_v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(A.ent + x_) + lane16); \
     }                                                                            \
   } while (0)
-  // more units than the ring lists: every wave -- the manager too -- walks the table of step p_ itself, all slices
+  // a step swept AGAIN with every slice counted (pool overflow where slices were left out): every wave -- the manager
+  // too -- fetches the table of step p_ itself and walks it
 #define BLURRILY_COUNT_WALK(p_)                                                  \
   do {                                                                           \
     uint32_t fa0_, fb0_, fa1_, fb1_, k_ = 0;                                     \
@@ -1708,10 +1764,12 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       ring->hdr[(s_) ^ 1u] = make_uint2(v1, 0u);                                 \
     }                                                                            \
     PHASE_MARK(7);                                  /* next step's units published */ \
+    TRACE_MARK(A, nd.q, (e_), 1u, 7u);                                           \
     const uint32_t chosen_ = my_i;                                               \
     BLURRILY_NEXT_VISIT(chosen_ + 1, my_i);                                      \
     if (my_i != chosen_ + 1) PATH_FLAG(A, nd.q, kPathSkipped);                   \
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), mcode, ta, tb, ta1, tb1);       \
+    PHASE_MARK(2);                                  /* step after the next chosen, its table requested */ \
   } while (0)
   // The manager settles the PENDING candidates of ring slot slot_ (step pstep_, whose windows left ls_ slices out,
   // noted in hot[hs_]): lane c takes candidate c -- in-window rank | parity << 16 | counted matches << 20 --, loads the
@@ -1721,25 +1779,29 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   // meanwhile can cost a settled candidate its place.  Done while the workers scan the next step.
 #define BLURRILY_PEND_SETTLE(slot_, hs_, pstep_, ls_)                            \
   do {                                                                           \
-    const uint32_t np_ = min(__builtin_amdgcn_readfirstlane(ctl->pend_n[slot_]), pend_cap); \
+    const uint32_t np_ = min(uint32_t(__builtin_amdgcn_readfirstlane(ctl->pend_n[slot_])), pend_cap); \
     if (np_) {                                                                   \
       const uint32_t* const pl_ = pend_list(ring, slot_, ring_units);            \
       for (uint32_t c_ = lane; c_ < np_; c_ += 64) {                             \
         const uint32_t e_ = pl_[c_];                                             \
         const uint32_t h_ = (e_ >> 16) & 1u, r16_ = e_ & 0xFFFFu;                \
         const uint32_t L_ = ((ls_) >> (4u * h_)) & 15u;                          \
+        /* where the left-out slices' postings start: two 16-byte reads, then the loads together */ \
+        const uint4 ha_ = *reinterpret_cast<const uint4*>(&ring->hot[hs_][h_][0]); \
+        const uint4 hb_ = *reinterpret_cast<const uint4*>(&ring->hot[hs_][h_][4]); \
+        const uint32_t hs8_[kNmMaxLeftOut] = {ha_.x, ha_.y, ha_.z, ha_.w, hb_.x, hb_.y, hb_.z, hb_.w}; \
         uint32_t w_[kNmMaxLeftOut];                                              \
         _Pragma("unroll") for (uint32_t k_ = 0; k_ < kNmMaxLeftOut; ++k_) {      \
           w_[k_] = 0;                                                            \
           if (k_ < L_)                                                           \
-            w_[k_] = reinterpret_cast<const uint32_t*>(A.ent + (ring->hot[hs_][h_][k_] - kBitmapSlots))[r16_ >> 5]; \
+            w_[k_] = reinterpret_cast<const uint32_t*>(A.ent + (hs8_[k_] - kBitmapSlots))[r16_ >> 5]; \
         }                                                                        \
         uint32_t cnt_ = e_ >> 20;                                                \
         _Pragma("unroll") for (uint32_t k_ = 0; k_ < kNmMaxLeftOut; ++k_) cnt_ += (w_[k_] >> (r16_ & 31u)) & 1u; \
         if (STATS(A)) atomicAdd(&STATS(A)[kStatProbes], static_cast<unsigned long long>(L_)); \
         const uint32_t rank_ = (pstep_) * kWPS * kWindowRanks + h_ * kWindowRanks + r16_; \
         const unsigned long long key_ = (static_cast<unsigned long long>(tc - min(tc, cnt_)) << 32) | rank_; \
-        bool pass_ = key_ <= ctl->thr;                                           \
+        bool pass_ = key_ <= thr_c;                                              \
         if (nd.has_floor) pass_ = pass_ && key_ > ctl->floor;                    \
         if (pass_) {                                     /* (tombstones were looked at where it was harvested) */ \
           const uint32_t at_ = atomicAdd(&ctl->adm_n, 1u);                       \
@@ -1755,13 +1817,19 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0;    // request counters (FindArgs::stats), wave-uniform
   // ---- the manager's state: the needle's codes, the table it will publish next and its visit index, the step before
   uint32_t mcode = 0, ta = 0, tb = 0, ta1 = 0, tb1 = 0, my_i = 0, p_prev = 0, ls_prev = 0;
+  uint32_t wm_l = 0, wm_base = 0xFFFFFFFFu;                     // win_max_tri of 64 visits (BLURRILY_LOAD_WMT)
+  // the threshold as scalars: set by compact_pool only, i.e. outside the hot loop -- read again behind every exit
+  unsigned long long thr_c = ctl->thr;
+  thr_c = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(uint32_t(thr_c >> 32))) << 32) |
+          __builtin_amdgcn_readfirstlane(uint32_t(thr_c));
   // ---- a worker's: its units of the step about to start (lane j: its j-th), the first of them loaded ahead
-  uint2 d_mine = make_uint2(0, 0);
+  uint4 tb_mine = make_uint4(0, 0, 0, 0);
+  uint32_t incl_mine = 0;
   uint4 pre_v = make_uint4(0, 0, 0, 0);
   uint32_t pre_h = 0;
   bool pre_live = false, pre_valid = false;
-  (void)mcode; (void)ta; (void)tb; (void)ta1; (void)tb1; (void)my_i; (void)p_prev; (void)ls_prev;
-  (void)d_mine; (void)pre_v; (void)pre_h; (void)pre_live; (void)pre_valid; (void)lane8; (void)lane16; (void)pend_cap;
+  (void)wm_l; (void)wm_base; (void)thr_c; (void)mcode; (void)ta; (void)tb; (void)ta1; (void)tb1; (void)my_i; (void)p_prev; (void)ls_prev;
+  (void)tb_mine; (void)incl_mine; (void)pre_v; (void)pre_h; (void)pre_live; (void)pre_valid; (void)lane8; (void)lane16; (void)pend_cap;
   if (MANAGER) PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
   if constexpr (MANAGER) {
     __builtin_amdgcn_s_setprio(3);                              // the wave everybody's next step waits for
@@ -1772,11 +1840,11 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     BLURRILY_FETCH_TABLE(BLURRILY_STEP_AT(my_i), mcode, ta, tb, ta1, tb1);
   }
   // a threshold exists (it is set by compact_pool only, i.e. outside the hot loop below: re-read behind every exit)
-  bool have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
+  bool have_thr = thr_c != kKeyInf;
   const uint32_t scan_cap = min(tc, ScanTraits<CT>::kMaxCount);  // a counter of this sweep cannot exceed it
   __syncthreads();
   uint2 h_next = ring->hdr[0];                                   // header of the step about to start
-  if constexpr (!MANAGER) d_mine = BLURRILY_MY_UNITS(0u);
+  if constexpr (!MANAGER) { tb_mine = BLURRILY_TAB(0u)[lane]; incl_mine = tab_incl(tb_mine); }
 
   // The sweep is a HOT LOOP of steps that need nothing special -- header, units (the manager: its turn), barrier,
   // scan with the published bound (the manager: the step before's pending candidates), barrier, a glance at the pool --
@@ -1794,37 +1862,46 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       if (p >= v1) { left = kLeftDone; break; }                 // no step left
       ++st_steps;
       PHASE_MARK(0);                                            // loop overhead
-      if (n_units == kRingWalk) { left = kLeftWalk; break; }
+      const bool tr_ = MANAGER || wid == 0;
+      if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 0u);
       if constexpr (MANAGER) {
         BLURRILY_MANAGER_TURN(e, s);
       } else {
         BLURRILY_COUNT_UNITS(s, n_units, true);
         PHASE_MARK(2);                                          // units counted
       }
+      if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 1u);
       lds_barrier();                                            // counts and next descriptors visible
+      if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 2u);
       PHASE_MARK(3);                                            // barrier after count
       // The next step's header and a worker's units of it were published before that barrier: requested now,
       // they arrive under the scan instead of standing, one LDS round trip each (several hundred clocks behind the
       // other workgroup's atomics), between the scan barrier and the first load of the next step.
       h_next = ring->hdr[s ^ 1u];
-      if constexpr (!MANAGER) d_mine = BLURRILY_MY_UNITS(s ^ 1u);
+      if constexpr (!MANAGER) tb_mine = BLURRILY_TAB(s ^ 1u)[lane];   // (its inclusive sums: BLURRILY_PRELOAD)
       if constexpr (MANAGER) {
         if (can_leave) BLURRILY_PEND_SETTLE(s ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);   // while the workers scan
         p_prev = p; ls_prev = n_units ? hy_ >> 24 : 0u;
       }
-      if (n_units == 0) continue;                               // nothing of the needle in this step's windows
+      if (n_units == 0) {                                       // nothing of the needle in this step's windows
+        if constexpr (!MANAGER) incl_mine = tab_incl(tb_mine);
+        continue;
+      }
       const uint32_t need = (hy_ >> 16) & 0xFFu;
       if (need == 0) { left = kLeftSlowScan; break; }
       if constexpr (!MANAGER) {
         const uint32_t wbase = p * kWPS * kWindowRanks;
         const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-        scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, scan_pool_cap, &ctl->pool_n,
+        scan_core<CT, NT>(cnt128, nd, (BLURRILY_X2 && have_thr) ? scan_cap + 1 : need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, scan_pool_cap, &ctl->pool_n,
                           &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr,
                           hy_ >> 24, pend_list(ring, s, ring_units), &ctl->pend_n[s], pend_cap, uint32_t(NT - 64));
+        if (tr_) TRACE_MARK(A, nd.q, e, 0u, 3u);
         BLURRILY_PRELOAD();
       }
+      if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 4u);
       PHASE_MARK(5);                                            // scan
       lds_barrier();                                            // counters are zero again
+      if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 5u);
       PHASE_MARK(6);                                            // barrier after scan
       // (Looking at the pool a count phase later -- the read requested here, used behind the next count barrier, a
       // compaction then running with the next step counted and not yet scanned -- was built and measured in round 3:
@@ -1832,6 +1909,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       const uint4 c_ = *reinterpret_cast<const uint4*>(&ctl->pool_n);          // pool_n, overflow, adm_n, (q)
       const uint32_t pn_ = __builtin_amdgcn_readfirstlane(c_.x) + __builtin_amdgcn_readfirstlane(c_.z);
       const uint32_t ov_ = __builtin_amdgcn_readfirstlane(c_.y);
+      if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 6u);
       if (ov_ != 0 || pn_ > sel_at || (!have_thr && pn_ >= A.keep)) { left = kLeftSelect; break; }
     }
     // ---- behind the hot loop: pending candidates first -- the manager's business, all waves wait ----------------
@@ -1842,7 +1920,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     const bool own_pending = can_leave && left == kLeftSelect && ctl->overflow == 0;   // (uniform: written behind barriers only)
     if (can_leave) {
       if constexpr (MANAGER) {
-        if (left == kLeftDone || left == kLeftWalk) BLURRILY_PEND_SETTLE((e & 1u) ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);
+        if (left == kLeftDone) BLURRILY_PEND_SETTLE((e & 1u) ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);
         if (left == kLeftSelect && !own_pending && lane == 0) ctl->pend_n[s] = 0;
         p_prev = p; ls_prev = 0;
       }
@@ -1853,13 +1931,6 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     pre_valid = false;                                          // (a unit loaded ahead is dropped)
     const uint32_t wbase = p * kWPS * kWindowRanks;
     const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-    if (left == kLeftWalk) {
-      if (MANAGER) PATH_FLAG(A, nd.q, kPathRingOverflow);
-      ++st_walk;
-      BLURRILY_COUNT_WALK(p);
-      if constexpr (MANAGER) BLURRILY_MANAGER_TURN(e, s);
-      __syncthreads();
-    }
     // kLeftSelect: the step is scanned, select_after_scan finds the pool as the hot loop saw it; else: scan first
     bool scanned = left == kLeftSelect;
     for (;;) {
@@ -1870,7 +1941,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       scanned = false;
       if (!select_after_scan<NT>(A, pool, ctl, wbase, wlen, nd.q, scan_pool_cap)) break;
       ++st_redo;                                                // pool overflow: sweep step p again -- every slice of it
-      if (n_units == kRingWalk || (hy_ >> 24) != 0) BLURRILY_COUNT_WALK(p);   // (the ring lists no units of left-out slices)
+      if ((hy_ >> 24) != 0) BLURRILY_COUNT_WALK(p);             // (the published table lists no units of left-out slices)
       else if constexpr (!MANAGER) BLURRILY_COUNT_UNITS(s, n_units, false);
       __syncthreads();
     }
@@ -1878,12 +1949,15 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       if constexpr (MANAGER) BLURRILY_PEND_SETTLE(s, e & 3u, p, hy_ >> 24);
       __syncthreads();
     }
-    have_thr = __builtin_amdgcn_readfirstlane(uint32_t(ctl->thr != kKeyInf)) != 0;
+    thr_c = ctl->thr;
+    thr_c = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(uint32_t(thr_c >> 32))) << 32) |
+            __builtin_amdgcn_readfirstlane(uint32_t(thr_c));
+    have_thr = thr_c != kKeyInf;
     ++e;
     h_next = ring->hdr[e & 1];                                  // (published behind step p's count barrier)
-    if constexpr (!MANAGER) d_mine = BLURRILY_MY_UNITS(e & 1);
+    if constexpr (!MANAGER) { tb_mine = BLURRILY_TAB(e & 1)[lane]; incl_mine = tab_incl(tb_mine); }
   }
-  PHASE_FLUSH(A);
+  if constexpr (MANAGER) PHASE_FLUSH_MANAGER(A); else PHASE_FLUSH(A);
   if (STATS(A) && lane == 0) {
     atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
     atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
@@ -1903,11 +1977,12 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
 #undef BLURRILY_PRELOAD
 #undef BLURRILY_PRODUCE
 #undef BLURRILY_LEAVE_OUT
-#undef BLURRILY_MY_UNITS
+#undef BLURRILY_UNIT_OF
+#undef BLURRILY_TAB
 #undef BLURRILY_PUBLISH_HDR
 #undef BLURRILY_FETCH_TABLE
 #undef BLURRILY_NEXT_VISIT
-#undef BLURRILY_WMT_AT
+#undef BLURRILY_LOAD_WMT
 #undef BLURRILY_STEP_AT
 }
 

@@ -30,7 +30,7 @@ def main():
     hay, off = W.geonames(n, max(1000, int(500000 * min(1.0, scale * 4))), 3)
     m = RawMap()
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
-    for key in ("nm_cmin", "nm_dense", "wsweep"):                 # e.g. NM_CMIN=0: nothing left out of the needle-major count
+    for key in ("nm_cmin", "nm_dense", "wsweep", "nm_min_windows", "ws_autotune"):                 # e.g. NM_CMIN=0: nothing left out of the needle-major count
         if os.environ.get(key.upper()):
             try:
                 m.set_option(key, int(os.environ[key.upper()]))
@@ -47,8 +47,9 @@ def main():
         rows, counts = m.find_batch_packed(qp, qo, 10)
         dt = time.perf_counter() - t
         nwg = min(batch, 512)
-        buf = np.zeros((nwg, 16), dtype=np.uint64)
-        assert lib.blurrily_debug_phase_clocks(m.handle, buf.ctypes.data, nwg) == 0
+        full = np.zeros((4096 + nwg, 16), dtype=np.uint64)           # rows 4096..: sweep_role's manager waves
+        assert lib.blurrily_debug_phase_clocks(m.handle, full.ctypes.data, 4096 + nwg) == 0
+        buf, mgr = full[:nwg], full[4096:]
         tot_all = buf.sum(axis=0).astype(np.float64)
         tot = tot_all[:8]
         per_window = tot / (batch * info["n_windows"])
@@ -56,6 +57,12 @@ def main():
         for name, v in zip(PHASES, per_window):
             print(f"   {name:22s} {v:9.0f}")
         print(f"   {'TOTAL':22s} {per_window.sum():9.0f}")
+        if mgr.sum():
+            mg = mgr.sum(axis=0).astype(np.float64)[:8] / (batch * info["n_windows"])
+            print("   manager wave (sweep_role): " + "  ".join(f"{nm_} {v:.0f}" for nm_, v in zip(
+                ["loop", "-", "choose+fetch", "barrier(count)", "-", "settle", "barrier(scan)", "publish"], mg)) + f"  TOTAL {mg.sum():.0f}")
+        st = m.find_stats()
+        print(f"   steps/needle {st['steps'] / batch:.1f} postings/needle {st['posting_entries'] / batch:.0f} last_sweep {m.get_option('last_sweep')}")
         per_needle = tot_all[10:13] / batch
         print(f"   per needle: setup {per_needle[0]:9.0f}  sweeps {per_needle[1]:9.0f}  final compaction + rows {per_needle[2]:9.0f}")
         if tot_all[8]:
