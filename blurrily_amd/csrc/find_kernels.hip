@@ -64,17 +64,6 @@
 #define BLURRILY_KERNELS_END
 #endif
 
-// (temporary, timing only -- results wrong: bounds of what a step's chain has to gain)
-#ifndef BLURRILY_X1
-#define BLURRILY_X1 0
-#endif
-#ifndef BLURRILY_X2
-#define BLURRILY_X2 0
-#endif
-#ifndef BLURRILY_X4
-#define BLURRILY_X4 0
-#endif
-
 // (temporary) trace build of the TIMED kernels: shader-clock stamps of the steps of needles [kTraceQ0, kTraceQ0 + 64),
 // wave 0 (role 0) and the manager wave (role 1), eight marks per step, 64 steps per needle
 #if defined(BLURRILY_TRACE) && !defined(BLURRILY_COUNTED)
@@ -1633,7 +1622,21 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   // L; what it finds goes to the step's pending list, and the manager settles its exact count from the left-out
   // slices' bitmaps during the next step (PEND_SETTLE).  Lane t ranks its slice among the window's dense ones by size
   // (one readlane per dense slice); the chosen ones note where their postings start (UnitRing::hot) and list no units.
-#define BLURRILY_LEAVE_OUT(hs_, h_, A_, B_, units_)                              \
+#define BLURRILY_LEAVE_OUT(hs_, h_, A_, rk_, units_)                             \
+  do {                                                                           \
+    const bool skip_ = (rk_) < l_max_;                                           \
+    const unsigned long long sm_ = __ballot(skip_);                              \
+    if (skip_) {                                                                 \
+      ring->hot[hs_][h_][__builtin_amdgcn_mbcnt_hi(uint32_t(sm_ >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(sm_), 0u))] = (A_); \
+      units_ = 0;                                                                \
+    }                                                                            \
+    ls_ |= uint32_t(__popcll(sm_)) << (4u * (h_));                               \
+  } while (0)
+  // A slice's rank by size among the dense slices of its window (lane t: trigram t's; 0xFF: not dense) -- what
+  // BLURRILY_LEAVE_OUT holds against l_max_.  It does not depend on the threshold, so the manager works it out for the
+  // table it will publish NEXT while the workers scan (it has the time there: the count barrier is the one that waits
+  // for it), one v_readlane per dense slice of the window.
+#define BLURRILY_RANK_ONE(A_, B_, rk_)                                           \
   do {                                                                           \
     const uint32_t size_ = (B_) - (A_);                                          \
     const bool dense_ = size_ >= A.nm_dense;                                     \
@@ -1643,13 +1646,13 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       const uint32_t su_ = __builtin_amdgcn_readlane(size_, u_);                 \
       bigger_ += (su_ > size_ || (su_ == size_ && u_ < lane)) ? 1u : 0u;         \
     }                                                                            \
-    const bool skip_ = dense_ && bigger_ < l_max_;                               \
-    const unsigned long long sm_ = __ballot(skip_);                              \
-    if (skip_) {                                                                 \
-      ring->hot[hs_][h_][__builtin_amdgcn_mbcnt_hi(uint32_t(sm_ >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(sm_), 0u))] = (A_); \
-      units_ = 0;                                                                \
-    }                                                                            \
-    ls_ |= uint32_t(__popcll(sm_)) << (4u * (h_));                               \
+    rk_ = dense_ ? bigger_ : 0xFFu;                                              \
+  } while (0)
+#define BLURRILY_RANK()                                                          \
+  do {                                                                           \
+    BLURRILY_RANK_ONE(ta, tb, rk0);                                              \
+    if (kNib) BLURRILY_RANK_ONE(ta1, tb1, rk1);                                  \
+    ranked = true;                                                               \
   } while (0)
   // the manager publishes the step's slice table into ring slot s_ (a lane's even-window units come first, then its
   // odd-window units)
@@ -1661,9 +1664,11 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
     uint32_t ls_ = 0;                                                            \
     const uint32_t l_max_ = (can_leave && thr_ != kKeyInf && need_ > A.nm_cmin) ? min(need_ - A.nm_cmin, kNmMaxLeftOut) : 0u; \
     if (l_max_) {                                                                \
-      BLURRILY_LEAVE_OUT(hs_, 0u, A0, B0, units0_);                              \
-      if (kNib) BLURRILY_LEAVE_OUT(hs_, 1u, A1, B1, units1_);                    \
+      if (!ranked) BLURRILY_RANK();            /* (the first step of a sweep, the one behind a rare path) */ \
+      BLURRILY_LEAVE_OUT(hs_, 0u, A0, rk0, units0_);                             \
+      if (kNib) BLURRILY_LEAVE_OUT(hs_, 1u, A1, rk1, units1_);                   \
     }                                                                            \
+    ranked = false;                            /* (the table is about to be replaced) */ \
     if (thr_ == kKeyInf && !nd.has_floor && !A.tomb && tc > 1) need_ = 0;        \
     const uint32_t incl_ = wave_inclusive_sum(units0_ + units1_);                \
     const uint32_t total_ = __builtin_amdgcn_readlane(incl_, 63);                \
@@ -1699,7 +1704,6 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       }                                                                          \
       k_ = wid + kWorkers;                                                       \
     }                                                                            \
-    if (BLURRILY_X4 && (have_mine_) && pre_valid) k_ = (n_);                     \
     pre_valid = false;                                                           \
     for (; k_ < (n_); k_ += kWorkers) {                                          \
       uint32_t x_, y_, h_;                                                       \
@@ -1817,6 +1821,8 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   uint32_t st_ent = 0, st_tab = 0, st_steps = 0, st_redo = 0, st_walk = 0;    // request counters (FindArgs::stats), wave-uniform
   // ---- the manager's state: the needle's codes, the table it will publish next and its visit index, the step before
   uint32_t mcode = 0, ta = 0, tb = 0, ta1 = 0, tb1 = 0, my_i = 0, p_prev = 0, ls_prev = 0;
+  uint32_t rk0 = 0xFFu, rk1 = 0xFFu;                            // ranks of the held table's slices (BLURRILY_RANK)
+  bool ranked = false;
   uint32_t wm_l = 0, wm_base = 0xFFFFFFFFu;                     // win_max_tri of 64 visits (BLURRILY_LOAD_WMT)
   // the threshold as scalars: set by compact_pool only, i.e. outside the hot loop -- read again behind every exit
   unsigned long long thr_c = ctl->thr;
@@ -1828,7 +1834,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   uint4 pre_v = make_uint4(0, 0, 0, 0);
   uint32_t pre_h = 0;
   bool pre_live = false, pre_valid = false;
-  (void)wm_l; (void)wm_base; (void)thr_c; (void)mcode; (void)ta; (void)tb; (void)ta1; (void)tb1; (void)my_i; (void)p_prev; (void)ls_prev;
+  (void)rk0; (void)rk1; (void)ranked; (void)wm_l; (void)wm_base; (void)thr_c; (void)mcode; (void)ta; (void)tb; (void)ta1; (void)tb1; (void)my_i; (void)p_prev; (void)ls_prev;
   (void)tb_mine; (void)incl_mine; (void)pre_v; (void)pre_h; (void)pre_live; (void)pre_valid; (void)lane8; (void)lane16; (void)pend_cap;
   if (MANAGER) PATH_FLAG(A, nd.q, kNib ? kPathNibble : kPathByte);
   if constexpr (MANAGER) {
@@ -1861,6 +1867,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       n_units = hy_ & 0xFFFFu;
       if (p >= v1) { left = kLeftDone; break; }                 // no step left
       ++st_steps;
+      if constexpr (MANAGER) __builtin_amdgcn_s_setprio(3);     // (the rare paths leave it at 0)
       PHASE_MARK(0);                                            // loop overhead
       const bool tr_ = MANAGER || wid == 0;
       if (tr_) TRACE_MARK(A, nd.q, e, MANAGER ? 1u : 0u, 0u);
@@ -1880,7 +1887,10 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       h_next = ring->hdr[s ^ 1u];
       if constexpr (!MANAGER) tb_mine = BLURRILY_TAB(s ^ 1u)[lane];   // (its inclusive sums: BLURRILY_PRELOAD)
       if constexpr (MANAGER) {
-        if (can_leave) BLURRILY_PEND_SETTLE(s ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);   // while the workers scan
+        if (can_leave) {                                        // while the workers scan
+          BLURRILY_PEND_SETTLE(s ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);
+          if (have_thr && n_units != 0 && ((hy_ >> 16) & 0xFFu) != 0) BLURRILY_RANK();   // (the table of the step after the next: fetched before the barrier)
+        }
         p_prev = p; ls_prev = n_units ? hy_ >> 24 : 0u;
       }
       if (n_units == 0) {                                       // nothing of the needle in this step's windows
@@ -1892,7 +1902,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       if constexpr (!MANAGER) {
         const uint32_t wbase = p * kWPS * kWindowRanks;
         const uint32_t wlen = min(kWPS * kWindowRanks, A.n_refs - wbase);
-        scan_core<CT, NT>(cnt128, nd, (BLURRILY_X2 && have_thr) ? scan_cap + 1 : need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, scan_pool_cap, &ctl->pool_n,
+        scan_core<CT, NT>(cnt128, nd, need, scan_cap, &ctl->thr, &ctl->floor, A.tomb, pool, scan_pool_cap, &ctl->pool_n,
                           &ctl->overflow, wbase, wlen, STATS(A) && A.path_flags ? &A.path_flags[nd.q] : nullptr,
                           hy_ >> 24, pend_list(ring, s, ring_units), &ctl->pend_n[s], pend_cap, uint32_t(NT - 64));
         if (tr_) TRACE_MARK(A, nd.q, e, 0u, 3u);
@@ -1976,6 +1986,8 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
 #undef BLURRILY_COUNT_UNITS
 #undef BLURRILY_PRELOAD
 #undef BLURRILY_PRODUCE
+#undef BLURRILY_RANK
+#undef BLURRILY_RANK_ONE
 #undef BLURRILY_LEAVE_OUT
 #undef BLURRILY_UNIT_OF
 #undef BLURRILY_TAB
