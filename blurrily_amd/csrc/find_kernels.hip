@@ -437,14 +437,14 @@ __device__ __forceinline__ uint32_t hi_half_shl(uint32_t v) {
   uint32_t out;
   const uint32_t sh = SH;
   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-      : "=v"(out) : "v"(sh), "v"(v));
+      : "=v"(out) : "s"(sh), "v"(v));
   return out;
 }
 
 // value >> (amount & 31), the AND being the hardware's
 __device__ __forceinline__ uint32_t shr_low5(uint32_t value, uint32_t amount) {
   uint32_t out;
-  asm("v_lshrrev_b32 %0, %1, %2" : "=v"(out) : "v"(amount), "v"(value));
+  asm("v_lshrrev_b32_e64 %0, %1, %2" : "=v"(out) : "v"(amount), "s"(value));   // (the constant from a scalar register: it costs no VGPR)
   return out;
 }
 
