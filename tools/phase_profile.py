@@ -27,7 +27,11 @@ def main():
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     nq = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
     n = int(8423769 * scale)
-    hay, off = W.geonames(n, max(1000, int(500000 * min(1.0, scale * 4))), 3)
+    if os.environ.get("PH_WORKLOAD"):                                  # e.g. words, skewed: bench.py's haystacks
+        hay, off = W.bench_haystack(os.environ["PH_WORKLOAD"], scale)
+        n = len(off) - 1
+    else:
+        hay, off = W.geonames(n, max(1000, int(500000 * min(1.0, scale * 4))), 3)
     m = RawMap()
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     for key in ("nm_cmin", "nm_dense", "wsweep", "nm_min_windows", "ws_autotune"):                 # e.g. NM_CMIN=0: nothing left out of the needle-major count
