@@ -449,7 +449,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // With "ws_autotune" 0, for smaller batches, and while request counters are collected on an unmeasured class, the
     // static rules apply: window-major by the measured table's mean_hit_slice rule, slices left out from 256 windows.
     const uint32_t cmin_opt = m->nm_cmin;
-    const bool leave_possible = ranges <= 1 && cmin_opt != 0 && limit <= 64 && ix.n_bitmaps != 0;
+    const bool leave_possible = ranges <= 1 && cmin_opt != 0 && limit <= 1024 && find_can_leave(limit) && ix.n_bitmaps != 0;
     const bool ws_possible = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.n_bitmaps != 0 &&
                              m->build_opt.ws_can_run(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
     auto run_sweep = [&](int which) -> int {           // 1 plain, 2 window-major, 3 slices left out

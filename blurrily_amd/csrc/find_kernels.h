@@ -124,6 +124,7 @@ enum : uint32_t {
 };
 
 uint32_t find_pool_cap(uint32_t keep);
+bool find_can_leave(uint32_t keep);   // limits whose pool leaves room for the needle-major sweep's settled candidates (up to ~150)
 int find_threads();
 uint32_t find_wgs_per_cu();   // resident byte-counter workgroups per CU (LDS and wave limits)   // workgroup size of the find kernel (BLURRILY_FIND_THREADS, default 1024)
 int launch_tokenise(const TokeniseArgs& t, hipStream_t stream);

@@ -405,7 +405,10 @@ template <> struct ScanTraits<Nib> {
 
 // sweep_coop's pending lists (candidates of a step that left slices out of its count, waiting for their bitmap
 // words), one per ring slot, and the pool's tail that takes the ones that pass (compact_pool)
-constexpr uint32_t kPendMax = 128, kAdmMax = 128;
+constexpr uint32_t kPendMax = 128;
+// (the pool's tail of settled candidates: it has to hold the keys a glance lets pass -- select_at() -- beside a step's
+// pending list; 128 slots of the 512-entry pool of limits up to 64, 256 of the 1 024-entry pool of limits up to ~150)
+__host__ __device__ constexpr uint32_t adm_max(uint32_t pool_cap) { return pool_cap <= 512 ? 128u : 256u; }
 
 // A candidate is one 64-bit key: (T - matches) in the high word, rank in the low word.  Ranks
 // follow (weight, reference), so ascending keys are the reference's result order.
@@ -1083,7 +1086,8 @@ __device__ void sweep_pipelined(const FindArgs& A, const Needle& nd, const uint1
 // itself (BLURRILY_COUNT_WALK).
 constexpr uint32_t kRingUnitsMax = 512;
 __host__ __device__ constexpr uint32_t ring_units_for(uint32_t pool_cap) {
-  return pool_cap <= 512 ? kRingUnitsMax : pool_cap <= 1024 ? 384u : 256u;       // (multiples of the sixteen waves)
+  return pool_cap <= 512 ? kRingUnitsMax : 256u;                 // (multiples of the sixteen waves; 384 beside the 1 024-entry
+                                                                 //  pool made no difference at configs[4], and the pending lists need the room)
 }
 // Inclusive prefix sum over the 64 lanes of a wave with DPP moves (row shifts inside the rows of 16, then the two
 // row broadcasts of gfx9): ten VALU instructions, against six dependent ds_bpermute round trips for __shfl_up.
@@ -1125,7 +1129,7 @@ __device__ __forceinline__ uint32_t* pend_list(UnitRing* ring, uint32_t slot, ui
 // sweep_coop leaves slices out of a step's count only where the candidates that leaves pending are sure of their
 // place in the pool (sweep_role); the pool's last kAdmMax slots are then theirs
 __device__ __forceinline__ bool coop_can_leave(const FindArgs& A) {
-  return A.nm_cmin != 0 && A.pool_cap <= 512 && !A.own_only && select_at(A) + 32 <= kAdmMax;
+  return A.nm_cmin != 0 && A.pool_cap <= 1024 && !A.own_only && select_at(A) + 32 <= adm_max(A.pool_cap);
 }
 
 // A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight
@@ -1523,8 +1527,8 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
   // what those slots hold beside the keys a glance lets pass (select_at()); not in phase 1 of the window-major sweep.
   const uint32_t sel_at = select_at(A);
   const bool can_leave = coop_can_leave(A);
-  const uint32_t scan_pool_cap = can_leave ? A.pool_cap - kAdmMax : A.pool_cap;
-  const uint32_t pend_cap = can_leave ? min(kPendMax, kAdmMax - sel_at) : 0u;
+  const uint32_t scan_pool_cap = can_leave ? A.pool_cap - adm_max(A.pool_cap) : A.pool_cap;
+  const uint32_t pend_cap = can_leave ? min(kPendMax, adm_max(A.pool_cap) - sel_at) : 0u;
   // (the i-th step visited: upward from the needle's own length class, round the end.  Outward from it instead --
   // one step above, one below, by turns -- measured in round 3: 270.0 vs 253.2 ms per 500 k needles, 6.7 % slower;
   // downward from it, round the start: 292.7 ms, 16 % slower -- every window visited later lies BEHIND the threshold's
@@ -1809,7 +1813,7 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
         if (nd.has_floor) pass_ = pass_ && key_ > ctl->floor;                    \
         if (pass_) {                                     /* (tombstones were looked at where it was harvested) */ \
           const uint32_t at_ = atomicAdd(&ctl->adm_n, 1u);                       \
-          if (at_ < kAdmMax) pool[A.pool_cap - kAdmMax + at_] = key_;            \
+          if (at_ < adm_max(A.pool_cap)) pool[A.pool_cap - adm_max(A.pool_cap) + at_] = key_; \
         }                                                                        \
       }                                                                          \
       if (lane == 0) ctl->pend_n[slot_] = 0;                                     \
@@ -2158,7 +2162,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
         }
         BLURRILY_SWEEP(sw_a, sw_b, sw_st);
         if (pass == 0) {
-          compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, SHORT && LEAVE && coop_can_leave(A) ? A.pool_cap - kAdmMax : A.pool_cap);
+          compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, SHORT && LEAVE && coop_can_leave(A) ? A.pool_cap - adm_max(A.pool_cap) : A.pool_cap);
           if (tid == 0) ctl->pool_n = 0;
           __syncthreads();
         }
@@ -2171,7 +2175,7 @@ __global__ __launch_bounds__(NT, (sizeof(CT) == 1 ? NT / 128 : NT / 256)) void f
     PHASE_NEEDLE(11);
 
     // ---- emit: best `keep` in final order; weights are looked up only here ---------------
-    compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, SHORT && LEAVE && coop_can_leave(A) ? A.pool_cap - kAdmMax : A.pool_cap);
+    compact_pool<NT>(pool, ctl, A.pool_cap, A.keep, SHORT && LEAVE && coop_can_leave(A) ? A.pool_cap - adm_max(A.pool_cap) : A.pool_cap);
     __builtin_amdgcn_s_setprio(kSerialPrio);
     const uint32_t nres = ctl->pool_n;
     if (RANGED) {
@@ -3071,7 +3075,7 @@ __global__ void finalize_rows_kernel(const FindArgs A, const uint32_t n) {
 size_t find_dynamic_lds_bytes(uint32_t pool_cap) {
   static_assert(sizeof(Control) <= 64, "the unit ring sits 64 bytes behind the control block");
   return size_t(pool_cap) * 8 + 2 * kCodeChunk * 4 + 64 + sizeof(UnitRing) + 2 * size_t(ring_units_for(pool_cap)) * 8 +
-         (pool_cap <= 512 ? 2 * kPendMax * 4 : 0) + 16;   // (pending lists: only where slices can be left out)
+         (pool_cap <= 1024 ? 2 * kPendMax * 4 : 0) + 16;  // (pending lists: only where slices can be left out)
 }
 size_t find_lds_bytes(size_t counter_bytes, uint32_t pool_cap) {
   return size_t(kWindowSize) * counter_bytes + find_dynamic_lds_bytes(pool_cap);
@@ -3118,6 +3122,14 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
   return 0;
 }
 
+// whether a pass that keeps `keep` rows can leave slices out of the needle-major count (sweep_role: coop_can_leave): the
+// pool's tail has to hold what a glance lets pass beside a step's pending list
+bool find_can_leave(uint32_t keep) {
+  const uint32_t cap = find_pool_cap(keep);
+  const uint32_t sel = std::min(keep + std::max(6u, keep / 2), cap / 2);      // select_at()
+  return cap <= 1024 && sel + 32 <= adm_max(cap);
+}
+
 uint32_t find_pool_cap(uint32_t keep) {
   // (the small pool's spare LDS is the unit ring's; at limit 100 the ring gains nothing and 512 entries cost
   // 1.5 % in compactions, configs[4])
@@ -3153,7 +3165,7 @@ static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
     if (a.short_only) {
       // (slices can be left out of a step's count: a limit of at most 64 -- the 512-entry pool --, not phase 1 of the
       // window-major sweep; sweep_role's coop_can_leave asks the same)
-      const bool leave = a.nm_cmin != 0 && a.pool_cap <= 512 && !a.own_only;
+      const bool leave = a.nm_cmin != 0 && a.pool_cap <= 1024 && !a.own_only && find_can_leave(a.keep);
       if (a.ranges > 1) return leave ? launch_find_tr<CT, NT, true, true, true>(a, grid, stream)
                                      : launch_find_tr<CT, NT, true, true>(a, grid, stream);
       return leave ? launch_find_tr<CT, NT, false, true, true>(a, grid, stream)

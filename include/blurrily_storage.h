@@ -247,8 +247,9 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *                             and what its three sweeps took, in microseconds (0: that sweep could not run)
  *   "last_sweep"      get: which sweep the last large batch took (1 / 2 / 3 as above; 0: latency mode)
  *   "nm_cmin"         (3)     the needle-major sweep may leave the largest dense slices of a (needle, window) out of
- *                             the count -- at most need - nm_cmin of them, four at most -- and settle the candidates
- *                             that leaves pending through the slices' bitmaps; 0: never.  Limits up to 64
+ *                             the count -- at most need - nm_cmin of them, eight at most -- and settle the candidates
+ *                             that leaves pending through the slices' bitmaps; 0: never.  Limits up to 149 (the candidate pool's tail
+ *                             has to hold the settled candidates beside what a glance at the pool lets pass)
  *   "nm_dense"        (4096)  ... slices of at least this many postings only (not below "dense_min")
  *   "nm_min_windows"  (256)   ... and, where the choice is not measured, on images of at least this many windows
  *   "devices"         (1)     replicate the device image on the first n visible devices (replica k on device (primary

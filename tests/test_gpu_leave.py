@@ -67,7 +67,7 @@ def _mixed(hay, off, n_q, seed):
 
 
 @pytest.mark.parametrize("limit,cmin,dense", [(10, 3, 512), (10, 1, 256), (10, 2, 1024), (1, 3, 256), (3, 2, 512), (64, 3, 256),
-                                              (33, 3, 512), (10, 5, 256)])
+                                              (33, 3, 512), (10, 5, 256), (100, 3, 256), (128, 2, 512), (149, 3, 256)])
 def test_geonames_medium_all_rows_vs_oracle(limit, cmin, dense):
     hay, off = W.geonames(700000, 90000, 51)                   # 11 windows
     m, o = _pair(hay, off, dense_min=256, nm_cmin=cmin, nm_dense=dense)
@@ -85,6 +85,7 @@ def test_hot_trigram_haystack_and_massive_ties():
     q, qo = W.queries(hay, off, 6000, 54)
     _check(m, o, q, qo, 10)
     _check(m, o, q, qo, 64)
+    _check(m, o, q, qo, 100)                                    # (configs[4]'s limit: the 1 024-entry pool, a tail of 256)
     m.close()
 
 
@@ -93,13 +94,16 @@ def test_single_words_small_windows_and_latency_mode_is_left_alone():
     m, o = _pair(hay, off, dense_min=128, nm_cmin=2, nm_dense=128)
     q, qo = W.queries(hay, off, 20000, 56)
     _check(m, o, q, qo, 10)
-    # a handful of needles: latency mode (ranges), which leaves nothing out; a limit above 64 neither
+    # a handful of needles: latency mode (ranges), which leaves nothing out; a limit whose pool has no room for the
+    # settled candidates' tail (from 150 on) neither; limit 100 does (the 1 024-entry pool, a tail of 256)
     q2, qo2 = W.queries(hay, off, 40, 57)
     rows, counts = m.find_batch_packed(q2, qo2, 10)
     assert m.get_option("last_sweep") == 0
     want = o.batch(q2, qo2, limit=10)
     assert np.array_equal(counts, want["counts"])
-    rows, counts = m.find_batch_packed(q, qo, 100)
+    _check(m, o, q[:int(qo[4000])], qo[:4001], 100, expect_left_out=False)   # (the hundredth-best match of a word is a poor one: little to leave out)
+    assert m.get_option("last_sweep") == 3
+    rows, counts = m.find_batch_packed(q, qo, 200)
     assert m.get_option("last_sweep") == 1
     m.close()
 

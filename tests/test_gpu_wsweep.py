@@ -228,10 +228,10 @@ def test_the_sweep_is_chosen_by_measurement_and_the_static_rule_holds_without_it
             choice = m.get_option("ws_choice")
             if cls is not None:
                 picked = (choice >> (2 * cls)) & 3
-                measured = eligible or (limit <= 64 and info["n_bitmaps"] > 0)     # something besides the plain sweep can run
+                measured = eligible or (limit <= 149 and info["n_bitmaps"] > 0)     # something besides the plain sweep can run
                 assert (picked != 0) == measured, (gen.__name__, n_q, limit, choice)
                 assert picked != 2 or eligible
-                assert picked != 3 or limit <= 64
+                assert picked != 3 or limit <= 149
             rows2, counts2 = m.find_batch_packed(q, qo, limit)                # (the chosen one)
             assert m.get_option("ws_choice") == choice
             live = np.arange(limit)[None, :] < counts[:, None].astype(np.int64)
