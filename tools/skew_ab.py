@@ -1,4 +1,4 @@
-"""configs[4] (hot-trigram haystack, limit 100) through each sweep of the library, rows compared with the plain sweep's.
+"""A bench workload (SK_WORKLOAD: skewed = configs[4], hot-trigram haystack, limit 100; words; geonames) through each sweep of the library, rows compared with the plain sweep's.
 python tools/skew_ab.py   (GPU box; SK_N needles = 100000, SK_LIMIT = 100)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,12 +8,13 @@ import workloads as W
 from blurrily_amd import RawMap
 
 n_q = int(os.environ.get("SK_N", "100000")); limit = int(os.environ.get("SK_LIMIT", "100"))
-hay, off = W.bench_haystack("skewed", 1.0)
+wl = os.environ.get("SK_WORKLOAD", "skewed")
+hay, off = W.bench_haystack(wl, 1.0)
 n = len(off) - 1
-q, qo = W.bench_needles(hay, off, "skewed", 1.0, 0, 1)
+q, qo = W.bench_needles(hay, off, wl, 1.0, 0, 1)
 q, qo = q[:int(qo[n_q])], qo[:n_q + 1]
 base = None
-for name, opts in (("plain", dict(wsweep=0, nm_cmin=0)), ("window-major", dict(ws_min_slice=0, ws_static_slice=0)),
+for name, opts in (("plain", dict(wsweep=0, nm_cmin=0)), ("window-major", dict(ws_min_slice=0, ws_static_slice=0, ws_min_windows=1)),
                    ("slices left out", dict(wsweep=0, nm_min_windows=0))):
     m = RawMap()
     m.set_option("ws_autotune", 0)
