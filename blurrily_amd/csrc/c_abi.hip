@@ -115,6 +115,8 @@ struct trigram_map_t {
   uint32_t    ws_cmin = 3;              // a left-out slice must leave at least this many counted matches
   uint32_t    nm_cmin = 3;              // the same for the needle-major sweep (0: it leaves nothing out)
   uint32_t    nm_dense = 4096;          // ... which leaves out slices of at least this many postings only
+  bool        small_sweep = true;       // images of at most kSmallMaxWindows windows: find_small_kernel serves large batches at limits up to 64
+  uint32_t    small_min_needles = 4096; // ... from this many needles on (below: two chains per CU are not the limit)
   uint32_t    nm_min_windows = 256;     // ... and, where the choice is not measured, on images of at least this many windows
   uint32_t    ws_min_needles = 16384;   // smaller batches: needle-major
   bool        ws_autotune = true;       // measure the choice per class of batch on first use (run_find_on)
@@ -285,15 +287,16 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   if (m->ws_codes.reserve(align_up(code_slots * sizeof(uint16_t), 256), stream) < 0) return -1;
   const size_t per_n = align_up(n * sizeof(uint32_t), 256);
   const bool multi_pass = limit > 256;             // long needles keep 256 rows per pass, short ones 1024
-  const size_t small_bytes = per_n * 5 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
+  const size_t small_bytes = per_n * 6 + (multi_pass ? align_up(n * 8, 256) : 0) + 256;
   if (m->ws_small.reserve(small_bytes, stream) < 0) return -1;
   unsigned char* sp = static_cast<unsigned char*>(m->ws_small.p);
-  uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1]=mid_count [2..]=queues
+  uint32_t* scalars  = reinterpret_cast<uint32_t*>(sp);            sp += 256;   // [0]=big_count [1]=mid_count [2]=over_count [3..]=queues
   uint32_t* q_ntri   = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* q_nb_ws  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* big_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* mid_list = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
   uint32_t* q_start  = reinterpret_cast<uint32_t*>(sp);            sp += per_n;
+  uint32_t* over_list = reinterpret_cast<uint32_t*>(sp);           sp += per_n;   // (small-haystack sweep: needles of 16..64 trigrams)
   unsigned long long* floor = nullptr;
   if (multi_pass) floor = reinterpret_cast<unsigned long long*>(sp);
   uint32_t* q_nb = d_nb ? d_nb : q_nb_ws;
@@ -334,12 +337,12 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     a.phase_clocks = m->d_phase;
   }
 #endif
-  // every launch gets its own zeroed queue word (scalars[2..63]); recycled in stream order
-  uint32_t queue_slot = 2;
+  // every launch gets its own zeroed queue word (scalars[3..63]); recycled in stream order
+  uint32_t queue_slot = 3;
   auto next_queue = [&]() -> uint32_t* {
     if (queue_slot >= 64) {
-      if (hipMemsetAsync(scalars + 2, 0, 248, stream) != hipSuccess) return nullptr;
-      queue_slot = 2;
+      if (hipMemsetAsync(scalars + 3, 0, 244, stream) != hipSuccess) return nullptr;
+      queue_slot = 3;
     }
     return scalars + queue_slot++;
   };
@@ -434,6 +437,28 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       }
       return 0;
     };
+    // An image of a few windows, a large batch, a limit of at most 64: the small-haystack sweep (find_small_kernel) --
+    // four waves and one window's 4-bit counters per needle, four needles' chains per CU instead of two -- for the
+    // needles of at most 15 trigrams; the ones it lists (16..64) follow through the byte-counter kernel.
+    auto run_small = [&]() -> int {
+      a.work_list = nullptr; a.n_work_dev = nullptr; a.n_work = uint32_t(n);
+      a.pass_base = 0; a.keep = limit; a.pool_cap = find_pool_cap(limit);
+      a.over_list = over_list; a.over_count = scalars + 2;
+      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+      if ((cb ? counted::launch_find_small(a, uint32_t(m->n_cus), stream) : launch_find_small(a, uint32_t(m->n_cus), stream)) < 0) return -1;
+      a.work_list = over_list; a.n_work_dev = scalars + 2; a.n_work = 0;
+      a.over_list = nullptr; a.over_count = nullptr;
+      if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+      a.short_only = 1;
+      if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+      a.short_only = 0;
+      if (maybe_mid) {                                 // 65..127: the tokeniser's mid list
+        a.work_list = mid_list; a.n_work_dev = scalars + 1; a.n_work = 0;
+        if (!(a.queue = next_queue())) { errno = EIO; return -1; }
+        if (do_launch_find(cb, a, false, uint32_t(std::min<size_t>(n, wgs)), stream) < 0) return -1;
+      }
+      return 0;
+    };
     // WHICH sweep serves the batch's short needles.  Three can: the needle-major sweep as it was through round 3
     // (1: every posting of every needle trigram counted), the needle-major sweep that leaves the largest dense
     // slices out of a step's count and settles candidates through bitmaps (3: "nm_cmin" > 0, limits up to 64), and
@@ -452,13 +477,18 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     const bool leave_possible = ranges <= 1 && cmin_opt != 0 && limit <= 1024 && find_can_leave(limit) && ix.n_bitmaps != 0;
     const bool ws_possible = ranges <= 1 && limit <= kWsMaxKeep && n >= m->ws_min_needles && ix.n_bitmaps != 0 &&
                              m->build_opt.ws_can_run(ix.n_windows, ix.mean_hit_slice) && code_slots < 0xFFFFFFFFull;
-    auto run_sweep = [&](int which) -> int {           // 1 plain, 2 window-major, 3 slices left out
+    auto run_sweep = [&](int which) -> int {           // 1 plain, 2 window-major, 3 slices left out, 4 small haystack
       a.nm_cmin = which == 3 ? cmin_opt : 0u;
-      return which == 2 ? run_ws() : run_nm();
+      return which == 2 ? run_ws() : which == 4 ? run_small() : run_nm();
     };
     int choice = 1;
     a.nm_cmin = 0;                                     // (latency mode and the long-needle launches leave nothing out)
-    if (ranges <= 1) {
+    const bool small_possible = ranges <= 1 && m->small_sweep && ix.n_windows <= kSmallMaxWindows && limit <= kSmallMaxKeep &&
+                                n >= m->small_min_needles;
+    if (small_possible) {
+      if (run_sweep(4) < 0) return -1;
+      if (is_base) m->last_sweep = 4;
+    } else if (ranges <= 1) {
       // (a chunk of a host-buffer batch belongs to the class of the WHOLE batch: class_hint)
       const size_t n_cls = std::max(n, m->class_hint);
       const double slice_factor = (n_cls < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
@@ -638,7 +668,7 @@ int ensure_replicas(trigram_map m) {
     // options and measured choices follow the primary's
     s->build_opt = m->build_opt; s->ws_cmin = m->ws_cmin; s->nm_cmin = m->nm_cmin; s->nm_dense = m->nm_dense;
     s->ws_min_needles = m->ws_min_needles; s->ws_autotune = m->ws_autotune; s->ws_static_slice = m->ws_static_slice;
-    s->nm_min_windows = m->nm_min_windows;
+    s->nm_min_windows = m->nm_min_windows; s->small_sweep = m->small_sweep; s->small_min_needles = m->small_min_needles;
     for (int c = 0; c < 6; ++c) if (m->ws_choice[c]) s->ws_choice[c] = m->ws_choice[c];
     s->n_cus = 0;
     if (r.base_builds != m->base_builds || s->dev.device < 0) {
@@ -1197,7 +1227,7 @@ constexpr OptionSlot kMapOptions[] = {
     {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0},
     {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64},
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
-    {"tuned_leave_us", 0, 0}};
+    {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1236,6 +1266,8 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 13: m->n_devices = uint32_t(value); return 0;   // (replicas are made, or dropped, by the next large batch)
     case 14: m->nm_min_windows = uint32_t(value); break;
     case 15: case 16: case 17: case 18: return 0;        // (read-only: what the last measurement saw)
+    case 19: m->small_sweep = value != 0; break;
+    case 20: m->small_min_needles = uint32_t(std::min<long long>(value, 0xFFFFFFFFll)); break;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1274,6 +1306,8 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 16: case 17: case 18:                             // microseconds of the sweep in that measurement (0: it could not run)
       *value = m->last_tuned < 0 ? 0 : (long long)(1000.0 * m->ws_tuned_ms[m->last_tuned][FIND_OPTION(kMapOptions, key) - 16]);
       return 0;
+    case 19: *value = m->small_sweep; return 0;
+    case 20: *value = m->small_min_needles; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -72,6 +72,10 @@ struct FindArgs {
   uint32_t        ranges;      // 0/1: off
   unsigned long long* part_keys;   // [n_items * ranges * keep] best keys of every task
   uint32_t*       part_count;  // [n_items * ranges]
+  // small-haystack sweep (find_small_kernel): needles it does not own (16..64 distinct trigrams) are listed here for the
+  // byte-counter launch that follows
+  uint32_t*       over_list;   // [n]
+  uint32_t*       over_count;  // [1] zeroed before launch
   unsigned long long* phase_clocks;  // profiling builds only (make profile), else nullptr
   // optional request counters of a launch (nullptr: off; see kStat* below) -- what the kernels asked of
   // the memory system and of the LDS, counted exactly from wave-uniform values
@@ -105,6 +109,7 @@ enum : uint32_t {
   kPathWsWide       = 1u << 19,   //   ... byte counters over the two halves of the window
   kPathWsTableWalk  = 1u << 20,   //   ... more than 64 units: the waves walked the published slice table
   kPathNmLeftOut    = 1u << 21,   // needle-major sweep: a candidate settled through the bitmaps of left-out slices
+  kPathSmall        = 1u << 22,   // small-haystack sweep (find_small_kernel: four waves per needle, one window per step)
 };
 
 // slots of FindArgs::stats
@@ -133,6 +138,10 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
                      hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
+// Small-haystack sweep over needles [0, a.n_work): four waves and one window's 4-bit counters per needle, four workgroups
+// per CU; needles with 16..64 distinct trigrams are appended to a.over_list.  keep <= kSmallMaxKeep, single pass.
+int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream);
+constexpr uint32_t kSmallMaxKeep = 64, kSmallMaxWindows = 8;
 // Window-major sweep of window `w` over needles [0, n) (those with <= 64 distinct trigrams); a.queue must
 // be a zeroed word of its own.  own_pass: only the needles whose own length class lives in this window
 // pair -- the launches that seed the states (counts[] zeroed before the first of them); else the others.
@@ -144,6 +153,7 @@ constexpr uint32_t kWsMaxKeep = 128;   // largest limit the window-major sweep s
 // the same launches of the build that keeps FindArgs::stats (find_kernels_counted.hip)
 namespace counted {
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
+int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream);
 int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, bool own_pass, hipStream_t stream);
 int launch_finalize_rows(const FindArgs& a, uint32_t n, hipStream_t stream);
 }

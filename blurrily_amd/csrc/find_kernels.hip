@@ -3054,6 +3054,223 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
 }
 #undef WS_CLOCK
 
+// ============================================================ small haystacks ================
+// An image of a few windows (configs[1]: 235 k words, four windows): the needle-major kernel above sweeps such a needle
+// in two steps, and what a needle costs is its CHAIN -- queue pop, scalars, codes, slice table, units, rows: six
+// dependent global round trips of ~2 800 clocks each, the cold start's bisection, two scans, two compactions: ~41 000
+// clocks -- of which a CU runs two at a time (its LDS holds two workgroups' counters) and is otherwise idle: a fifth of
+// the LDS pipe busy.  Here a needle gets FOUR waves and ONE window's 4-bit counters (32 KiB, wsweep_kernel's layout and
+// its robust pass: count every slice, scan to the pool against the threshold, cold start by bisection), so that four
+// needles' chains run per CU, each wave walking the needle's slice table itself (no publishing turn, no ring).  It owns
+// needles with at most 15 distinct trigrams (4 bits suffice whatever the window); the others are listed for the
+// byte-counter launch that follows (FindArgs::over_list).  Same answer by construction: every posting counted, every
+// counter held against the exact threshold, any window order.
+__global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const FindArgs A) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];
+  __shared__ unsigned long long s_pool[kWsPool];
+  __shared__ Control s_ctl;
+  __shared__ uint32_t s_tally[4];                        // the cold start's tallies, one per pass of the bisection
+  uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
+  Control* ctl = &s_ctl;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t keep = A.keep;
+  const uint32_t sel_at = min(keep + max(6u, keep / 2), kWsPool / 2);
+  constexpr uint32_t kVecs = kWsCntWords / 4 / kWsNT;    // a thread's vectors of the window's counters: eight
+  for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 4) s_tally[tid] = 0;
+  uint32_t st_ent = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0, st_tab = 0;
+  ws_barrier();
+  for (;;) {
+    if (tid == 0) ctl->q = atomicAdd(A.queue, 1u);
+    ws_barrier();
+    const uint32_t q = ctl->q;
+    ws_barrier();                                        // everyone has read q before it is rewritten
+    if (q >= A.n_work) break;
+    const uint32_t T = A.q_ntri[q];
+    if (T > 15) {                                        // byte counters: the launch that follows
+      if (tid == 0 && T <= 64) A.over_list[atomicAdd(A.over_count, 1u)] = q;
+      continue;
+    }
+    if (A.q_nb[q] == 0 || keep == 0) {
+      if (tid == 0) A.counts[q] = 0;
+      continue;
+    }
+    const uint32_t code = lane < T ? A.qcodes[A.offsets[q] + q + lane] : 0u;
+    if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; }
+    PATH_FLAG(A, q, kPathSmall | kPathNibble);
+    ++st_tasks;
+    // (the sweep starts at the needle's own length class only where there are enough windows for it to pay, as above)
+    const uint32_t qs = A.q_start[q];
+    const uint32_t ws = (A.n_windows >= 8 && qs < A.n_windows) ? qs : 0u;
+    uint32_t n_sorted = 0;                               // keys at the head of the pool that are in order
+    // slice table of the first window, every wave its own copy (lane t: trigram t); the next window's travels meanwhile
+    uint2 se = make_uint2(0, 0), se_next = make_uint2(0, 0);
+    if (lane < T) se = A.slice_se[size_t(ws) * kNumCodes + code];
+    // this wave's first two units of the window about to be counted, loaded a window ahead (while the one before is scanned)
+    uint4 h0 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair), h1 = h0;
+    bool head_ok = false;
+#define SMALL_LOAD_HEAD(ta_, tb_)                                                         \
+  do {                                                                                    \
+    uint32_t k_ = 0, x0_ = 0, y0_ = 0, x1_ = 0, y1_ = 0;                                  \
+    BLURRILY_FOR_SLOT_UNITS(kWsNW, ta_, tb_, wid, lane, k_, {                             \
+      x0_ = k_ == 0 ? c : x0_; y0_ = k_ == 0 ? sb : y0_;                                  \
+      x1_ = k_ == 1 ? c : x1_; y1_ = k_ == 1 ? sb : y1_;                                  \
+    });                                                                                   \
+    h0 = load_group(A.ent, x0_, y0_);                                                     \
+    h1 = load_group(A.ent, x1_, y1_);                                                     \
+    head_ok = true;                                                                       \
+  } while (0)
+    ws_barrier();                                        // the control block is set
+    for (uint32_t i = 0; i < A.n_windows; ++i) {
+      const uint32_t w = ws + i < A.n_windows ? ws + i : ws + i - A.n_windows;
+      const uint32_t wn = ws + i + 1 < A.n_windows ? ws + i + 1 : ws + i + 1 - A.n_windows;
+      if (i + 1 < A.n_windows && lane < T) se_next = A.slice_se[size_t(wn) * kNumCodes + code];
+      if (i + 1 >= A.n_windows) se_next = make_uint2(0, 0);
+      if (STATS(A)) st_tab += 2 * T;
+      const uint32_t wbase = w * kWindowRanks;
+      const uint32_t wlen = min(kWindowRanks, A.n_refs - wbase);
+      const uint32_t ta = se.x, tb = se.y;
+      se = se_next;
+      for (;;) {                                         // again after a pool overflow (rare)
+        const unsigned long long thr = ctl->thr;
+        const uint32_t need = matches_needed(thr, T, wbase);
+        if (min(T, A.win_max_tri[w]) < need) { PATH_FLAG(A, q, kPathSkipped); head_ok = false; break; }   // no reference of the window can get in
+        if (__ballot(tb > ta) == 0) { head_ok = false; break; }   // nothing of the needle in this window
+        ++st_steps;
+        // ---- count: unit j of slice t belongs to wave (t + j) mod 4; the first two are here already (or loaded now),
+        // the others are loaded and counted in place, one unit's atomics under the next one's load
+        {
+          if (!head_ok) SMALL_LOAD_HEAD(ta, tb);
+          head_ok = false;
+          uint32_t k = 0;
+          uint4 pend = h1;
+          ws_bump8<false>(s_cnt, h0, 0u);
+          BLURRILY_FOR_SLOT_UNITS(kWsNW, ta, tb, wid, lane, k, {
+            if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8));
+            if (k >= 2) {
+              const uint4 v = load_group(A.ent, c, sb);
+              ws_bump8<false>(s_cnt, pend, 0u);
+              pend = v;
+            }
+          });
+          ws_bump8<false>(s_cnt, pend, 0u);
+        }
+        // the next window's first units go out now: they travel under this window's scan
+        if (i + 1 < A.n_windows) SMALL_LOAD_HEAD(se.x, se.y);
+        ws_barrier();
+        // ---- scan: the thread's eight vectors of counters are read ONCE, together, and cleared at once; the cold start's
+        // bisection and the harvest work on the registers
+        const WsLayout<false> Y0(1u, 0u, wlen);
+        uint4 v[kVecs];
+#pragma unroll
+        for (uint32_t j = 0; j < kVecs; ++j) {
+          const uint32_t iv = tid + j * kWsNT;
+          v[j] = make_uint4(0, 0, 0, 0);
+          if (iv < Y0.nv) v[j] = cnt128[iv];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kVecs; ++j) {
+          const uint32_t iv = tid + j * kWsNT;
+          uint32_t z = 0;
+          asm volatile("" : "+v"(z));
+          if (iv < Y0.nv) cnt128[iv] = make_uint4(z, z, z, z);
+        }
+        v[kVecs - 1] = Y0.mask_pad(v[kVecs - 1], tid + (kVecs - 1) * kWsNT);
+        if (tid == 0 && Y0.nv < kWsCntWords / 4) s_cnt[kWsCntWords - 1] = 0;   // the padding slot's word (a short window)
+        uint32_t floor_need = need;
+        if (thr == kKeyInf && T > 1 && !A.tomb) {
+          // no threshold yet: only counters that can be among the window's best `keep` (cold_start_need's argument)
+          PATH_FLAG(A, q, kPathColdStart);
+          uint32_t lo = 1, hi = min(T, 15u), pass = 0;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            const WsLayout<false> Y(mid, 0u, wlen);
+            uint32_t mine = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kVecs; ++j)
+              mine += __popc(Y.hits(v[j].x)) + __popc(Y.hits(v[j].y)) + __popc(Y.hits(v[j].z)) + __popc(Y.hits(v[j].w));
+#pragma unroll
+            for (uint32_t dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, int(dd));
+            if (lane == 0 && mine) atomicAdd(&s_tally[pass], mine);
+            ws_barrier();
+            if (s_tally[pass] >= keep) lo = mid; else hi = mid - 1;
+            ++pass;                                      // (at most four passes: hi <= 15)
+          }
+          ws_barrier();                                  // everyone has read the last tally
+          if (tid < 4) s_tally[tid] = 0;
+          floor_need = max(floor_need, lo);
+        }
+        {
+          const WsLayout<false> Y(min(floor_need, 16u), 0u, wlen);
+#pragma unroll
+          for (uint32_t j = 0; j < kVecs; ++j) {
+            const uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            if (((d[0] | d[1] | d[2] | d[3]) & Y.pre) == 0) continue;
+#pragma unroll 1
+            for (uint32_t jj = 0; jj < 4; ++jj) {
+              uint32_t m = Y.hits(d[jj]);
+              while (m) {
+                const uint32_t bit = __ffs(m) - 1;
+                m &= m - 1;
+                ws_admit(A, ctl, s_pool, thr, T, wbase, Y.rank16(tid + j * kWsNT, jj, bit), Y.count(d[jj], bit));
+              }
+            }
+          }
+        }
+        ws_barrier();
+        const uint32_t ov = ctl->overflow, pn = ctl->pool_n;
+        if (!(ov || pn > sel_at || (thr == kKeyInf && pn >= keep))) break;
+        ws_barrier();                                    // (everyone has read the pool's state)
+        ++st_compact;
+        PATH_FLAG(A, q, ov ? kPathCompaction | kPathResweep : kPathCompaction);
+        ws_compact_pool(s_pool, ctl, keep, n_sorted);
+        n_sorted = ctl->pool_n;
+        if (!ov) break;
+        // the pool overflowed: candidates of this window were lost -- keep the tightened threshold, forget the
+        // window's survivors, sweep it again (every pass shrinks the admitted set)
+        ++st_redo;
+        head_ok = false;                                 // (the units loaded ahead are the NEXT window's)
+        if (tid == 0) {
+          uint32_t jj = 0;
+          const uint32_t np = ctl->pool_n;
+          for (uint32_t k2 = 0; k2 < np; ++k2)
+            if (uint32_t(s_pool[k2]) - wbase >= wlen) s_pool[jj++] = s_pool[k2];
+          ctl->pool_n = jj;
+        }
+        ws_barrier();
+        n_sorted = ctl->pool_n;
+      }
+    }
+#undef SMALL_LOAD_HEAD
+    // ---- emit: best `keep` in final order
+    ws_barrier();
+    ws_compact_pool(s_pool, ctl, keep, n_sorted);
+    const uint32_t nres = ctl->pool_n;
+    trigram_match_t* out = A.results + size_t(q) * A.limit;
+    if (tid < nres) {
+      const unsigned long long key = s_pool[tid];
+      const uint32_t rk = uint32_t(key);
+      trigram_match_t r;
+      r.reference = A.ref_of_rank[rk];
+      r.matches = T - uint32_t(key >> 32);
+      r.weight = A.weight_of_rank[rk];
+      out[tid] = r;
+    }
+    if (tid == 0) A.counts[q] = nres;
+    ws_barrier();                                        // pool reads done before the next needle resets it
+  }
+  if (STATS(A) && lane == 0) {
+    atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
+    atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));
+    if (wid == 0) {
+      atomicAdd(&STATS(A)[kStatSteps], static_cast<unsigned long long>(st_steps));
+      atomicAdd(&STATS(A)[kStatTasks], static_cast<unsigned long long>(st_tasks));
+      atomicAdd(&STATS(A)[kStatCompactions], static_cast<unsigned long long>(st_compact));
+      atomicAdd(&STATS(A)[kStatResweeps], static_cast<unsigned long long>(st_redo));
+    }
+  }
+}
+
 // keys -> rows, in place: a needle's keys occupy the first 8 bytes of every 12-byte row slot's
 // worth of its result area (2 words per key, packed), so rows are written from the last to the
 // first -- row i lands on keys >= i only.  One lane per needle.
@@ -3203,6 +3420,14 @@ int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, boo
   const uint32_t chunks = (n + chunk_len - 1) / chunk_len;
   const uint32_t grid = std::min(chunks, n_cus * 4u);
   hipLaunchKernelGGL(wsweep_kernel, dim3(grid), dim3(kWsNT), 0, stream, a, w, n, chunk_len, own_pass ? 1u : 0u);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream) {
+  if (a.n_work == 0) return 0;
+  const uint32_t grid = std::min(a.n_work, n_cus * 4u);       // four workgroups per CU (LDS: 35 KiB each)
+  hipLaunchKernelGGL(find_small_kernel, dim3(grid), dim3(kWsNT), 0, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -245,13 +245,16 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *                             2 window-major, 3 needle-major with slices left out); set 0: forget it
  *   "tuned_class", "tuned_nm_us", "tuned_ws_us", "tuned_leave_us"   get: the class measured most recently (-1: none)
  *                             and what its three sweeps took, in microseconds (0: that sweep could not run)
- *   "last_sweep"      get: which sweep the last large batch took (1 / 2 / 3 as above; 0: latency mode)
+ *   "last_sweep"      get: which sweep the last large batch took (1 / 2 / 3 as above, 4: the small-haystack sweep; 0: latency mode)
  *   "nm_cmin"         (3)     the needle-major sweep may leave the largest dense slices of a (needle, window) out of
  *                             the count -- at most need - nm_cmin of them, eight at most -- and settle the candidates
  *                             that leaves pending through the slices' bitmaps; 0: never.  Limits up to 149 (the candidate pool's tail
  *                             has to hold the settled candidates beside what a glance at the pool lets pass)
  *   "nm_dense"        (4096)  ... slices of at least this many postings only (not below "dense_min")
  *   "nm_min_windows"  (256)   ... and, where the choice is not measured, on images of at least this many windows
+ *   "small_sweep"     (1)     an image of at most eight windows serves batches of at least "small_min_needles" (4096)
+ *                             needles at limits up to 64 with four waves and one window's counters per needle -- four
+ *                             needles per CU at a time instead of two ("last_sweep" 4); 0: never
  *   "devices"         (1)     replicate the device image on the first n visible devices (replica k on device (primary
  *                             + k) mod visible) and shard every batch of at least 1 024 x n needles contiguously over
  *                             them: blurrily_storage_find_batch and _find_batch_device alike -- the rows land in the

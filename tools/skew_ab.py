@@ -14,8 +14,9 @@ n = len(off) - 1
 q, qo = W.bench_needles(hay, off, wl, 1.0, 0, 1)
 q, qo = q[:int(qo[n_q])], qo[:n_q + 1]
 base = None
-for name, opts in (("plain", dict(wsweep=0, nm_cmin=0)), ("window-major", dict(ws_min_slice=0, ws_static_slice=0, ws_min_windows=1)),
-                   ("slices left out", dict(wsweep=0, nm_min_windows=0))):
+for name, opts in (("plain", dict(wsweep=0, nm_cmin=0, small_sweep=0)),
+                   ("window-major", dict(ws_min_slice=0, ws_static_slice=0, ws_min_windows=1, small_sweep=0)),
+                   ("slices left out", dict(wsweep=0, nm_min_windows=0, small_sweep=0)), ("small haystack", dict())):
     m = RawMap()
     m.set_option("ws_autotune", 0)
     for k, v in opts.items():
