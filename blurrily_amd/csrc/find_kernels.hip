@@ -70,8 +70,12 @@
 #define TRACE_MARK(A, q_, e_, role_, mark_) do { if ((A).phase_clocks && (q_) - 200000u < 64u && (e_) < 64u) { \
     const unsigned long long t_ = clock64(); \
     if ((threadIdx.x & 63u) == 0) (A).phase_clocks[(((((q_) - 200000u) * 64u + (e_)) * 2u + (role_)) * 8u) + (mark_)] = t_; } } while (0)
+#define TRACE_MARK_AT(A, base_, q_, e_, role_, mark_) do { if ((A).phase_clocks && (q_) - (base_) < 64u && (e_) < 64u) { \
+    const unsigned long long t_ = clock64(); \
+    if ((threadIdx.x & 63u) == 0) (A).phase_clocks[(((((q_) - (base_)) * 64u + (e_)) * 2u + (role_)) * 8u) + (mark_)] = t_; } } while (0)
 #else
 #define TRACE_MARK(A, q_, e_, role_, mark_) do { } while (0)
+#define TRACE_MARK_AT(A, base_, q_, e_, role_, mark_) do { } while (0)
 #endif
 
 namespace blurrily {
@@ -2479,7 +2483,13 @@ __device__ __forceinline__ void ws_compact_pool(unsigned long long* pool, Contro
   const unsigned long long mine = tid < n ? pool[tid] : kKeyInf;
   uint32_t below = 0;
   if (tid < n) {
-    for (uint32_t j = n_sorted; j < n; ++j) below += pool[j] < mine;    // same address in every lane: a broadcast
+    uint32_t j = n_sorted;                                              // (same address in every lane: broadcasts)
+    if (j & 1u) { if (j < n) below += pool[j] < mine; ++j; }
+    for (; j + 2 <= n; j += 2) {                                        // two keys per read
+      const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(pool + j);
+      below += uint32_t(two.x < mine) + uint32_t(two.y < mine);
+    }
+    if (j < n) below += pool[j] < mine;
     if (tid < n_sorted) {
       below += tid;
     } else {
@@ -3065,11 +3075,15 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
 // needles with at most 15 distinct trigrams (4 bits suffice whatever the window); the others are listed for the
 // byte-counter launch that follows (FindArgs::over_list).  Same answer by construction: every posting counted, every
 // counter held against the exact threshold, any window order.
+constexpr uint32_t kSmallCand = 1024;
 __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const FindArgs A) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];
   __shared__ unsigned long long s_pool[kWsPool];
   __shared__ Control s_ctl;
   __shared__ uint32_t s_tally[4];                        // the cold start's tallies, one per pass of the bisection
+  __shared__ uint32_t s_nextq;
+  __shared__ uint32_t s_cand[kSmallCand];                // a window's counters at the bound: in-window rank | count << 16
+  __shared__ uint32_t s_ncand;                           // the queue slot popped for the needle after the current one
   uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
   Control* ctl = &s_ctl;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -3078,34 +3092,74 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   constexpr uint32_t kVecs = kWsCntWords / 4 / kWsNT;    // a thread's vectors of the window's counters: eight
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   if (tid < 4) s_tally[tid] = 0;
+  if (tid == 0) s_ncand = 0;
   uint32_t st_ent = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0, st_tab = 0;
   ws_barrier();
+  // The NEXT needle is set up while the current one is swept -- its queue pop, its scalars, its codes, its first slice
+  // table are four dependent global round trips (~2 800 clocks each under load) that a needle of four windows can ill
+  // afford in a row: one stage is advanced at the top of every window of the current sweep, whatever is left is caught up
+  // on when the needle's turn comes.  stage: 0 nothing yet, 1 pop issued (thread 0 holds the slot), 2 slot in LDS,
+  // 3 scalars requested, 4 codes requested, 5 table requested.
+  constexpr uint32_t kSmallChunk = 4;
+  uint32_t ch_base = 0, ch_left = 0;                     // (thread 0: what is left of the slots it took last)
+  uint32_t stage = 0, nx_pop = 0, nx_q = 0, nx_T = 0, nx_nb = 0, nx_qs = 0, nx_code = 0;
+  uint64_t nx_off = 0;
+  bool nx_ok = false;
+  uint2 nx_se = make_uint2(0, 0);
+#define SMALL_ADVANCE()                                                                   \
+  do {                                                                                    \
+    switch (stage) {                                                                      \
+      case 0:                                                                             \
+        if (tid == 0) {                    /* (slots are taken kSmallChunk at a time: see above) */ \
+          if (ch_left == 0) { ch_base = atomicAdd(A.queue, kSmallChunk); ch_left = kSmallChunk; } \
+          nx_pop = ch_base++; --ch_left;                                                  \
+        }                                                                                 \
+        stage = 1; break;                                                                 \
+      case 1: if (tid == 0) s_nextq = nx_pop; stage = 2; break;                           \
+      case 2:                                                                             \
+        ws_barrier();                                                                     \
+        nx_q = s_nextq;                                                                   \
+        nx_ok = nx_q < A.n_work;                                                          \
+        if (nx_ok) { nx_T = A.q_ntri[nx_q]; nx_nb = A.q_nb[nx_q]; nx_off = A.offsets[nx_q]; nx_qs = A.q_start[nx_q]; } \
+        stage = 3; break;                                                                 \
+      case 3:                                                                             \
+        nx_code = 0;                                                                      \
+        if (nx_ok && nx_T <= 15 && lane < nx_T) nx_code = A.qcodes[nx_off + nx_q + lane]; \
+        stage = 4; break;                                                                 \
+      case 4: {                                                                           \
+        nx_se = make_uint2(0, 0);                                                         \
+        const uint32_t ws_ = (A.n_windows >= 8 && nx_qs < A.n_windows) ? nx_qs : 0u;      \
+        if (nx_ok && nx_T <= 15 && nx_nb != 0 && lane < nx_T) nx_se = A.slice_se[size_t(ws_) * kNumCodes + nx_code]; \
+        stage = 5; break;                                                                 \
+      }                                                                                   \
+      default: break;                                                                     \
+    }                                                                                     \
+  } while (0)
   for (;;) {
-    if (tid == 0) ctl->q = atomicAdd(A.queue, 1u);
-    ws_barrier();
-    const uint32_t q = ctl->q;
-    ws_barrier();                                        // everyone has read q before it is rewritten
-    if (q >= A.n_work) break;
-    const uint32_t T = A.q_ntri[q];
+    while (stage < 5) SMALL_ADVANCE();                   // (the first needle; a needle whose setup the sweep before did not finish)
+    if (!nx_ok) break;
+    const uint32_t q = nx_q, T = nx_T, qs = nx_qs;
+    const bool empty = nx_nb == 0;
+    const uint32_t code = nx_code;
+    uint2 se = nx_se, se_next = make_uint2(0, 0);
+    stage = 0;
+    SMALL_ADVANCE();                                     // the pop for the needle after this one goes out at once
     if (T > 15) {                                        // byte counters: the launch that follows
       if (tid == 0 && T <= 64) A.over_list[atomicAdd(A.over_count, 1u)] = q;
       continue;
     }
-    if (A.q_nb[q] == 0 || keep == 0) {
+    if (empty || keep == 0) {
       if (tid == 0) A.counts[q] = 0;
       continue;
     }
-    const uint32_t code = lane < T ? A.qcodes[A.offsets[q] + q + lane] : 0u;
+    if (wid == 0) TRACE_MARK_AT(A, 50000u, q, 7u, 0u, 0u);
     if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; }
     PATH_FLAG(A, q, kPathSmall | kPathNibble);
     ++st_tasks;
     // (the sweep starts at the needle's own length class only where there are enough windows for it to pay, as above)
-    const uint32_t qs = A.q_start[q];
     const uint32_t ws = (A.n_windows >= 8 && qs < A.n_windows) ? qs : 0u;
     uint32_t n_sorted = 0;                               // keys at the head of the pool that are in order
     // slice table of the first window, every wave its own copy (lane t: trigram t); the next window's travels meanwhile
-    uint2 se = make_uint2(0, 0), se_next = make_uint2(0, 0);
-    if (lane < T) se = A.slice_se[size_t(ws) * kNumCodes + code];
     // this wave's first two units of the window about to be counted, loaded a window ahead (while the one before is scanned)
     uint4 h0 = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair), h1 = h0;
     bool head_ok = false;
@@ -3122,6 +3176,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   } while (0)
     ws_barrier();                                        // the control block is set
     for (uint32_t i = 0; i < A.n_windows; ++i) {
+      if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 0u);
+      SMALL_ADVANCE();                                   // one stage of the next needle's setup
+      if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 1u);
       const uint32_t w = ws + i < A.n_windows ? ws + i : ws + i - A.n_windows;
       const uint32_t wn = ws + i + 1 < A.n_windows ? ws + i + 1 : ws + i + 1 - A.n_windows;
       if (i + 1 < A.n_windows && lane < T) se_next = A.slice_se[size_t(wn) * kNumCodes + code];
@@ -3155,9 +3212,12 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
           });
           ws_bump8<false>(s_cnt, pend, 0u);
         }
+        if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 2u);
         // the next window's first units go out now: they travel under this window's scan
         if (i + 1 < A.n_windows) SMALL_LOAD_HEAD(se.x, se.y);
+        if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 3u);
         ws_barrier();
+        if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 4u);
         // ---- scan: the thread's eight vectors of counters are read ONCE, together, and cleared at once; the cold start's
         // bisection and the harvest work on the registers
         const WsLayout<false> Y0(1u, 0u, wlen);
@@ -3177,6 +3237,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
         }
         v[kVecs - 1] = Y0.mask_pad(v[kVecs - 1], tid + (kVecs - 1) * kWsNT);
         if (tid == 0 && Y0.nv < kWsCntWords / 4) s_cnt[kWsCntWords - 1] = 0;   // the padding slot's word (a short window)
+        if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 5u);
         uint32_t floor_need = need;
         if (thr == kKeyInf && T > 1 && !A.tomb) {
           // no threshold yet: only counters that can be among the window's best `keep` (cold_start_need's argument)
@@ -3200,24 +3261,66 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
           if (tid < 4) s_tally[tid] = 0;
           floor_need = max(floor_need, lo);
         }
+        if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 6u);
         {
+          // harvest in two phases: every thread LISTS its counters at the bound (one SWAR pass to count them, one atomic
+          // to reserve their places, a light loop to write rank | count), then the list is worked off a candidate per
+          // thread -- key, threshold, pool -- without the divergence of 256 threads walking 32 words each for the hits
+          // of a few (9 000 of a first window's 14 000 clocks)
           const WsLayout<false> Y(min(floor_need, 16u), 0u, wlen);
+          uint32_t n_hit = 0;
 #pragma unroll
-          for (uint32_t j = 0; j < kVecs; ++j) {
-            const uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-            if (((d[0] | d[1] | d[2] | d[3]) & Y.pre) == 0) continue;
-#pragma unroll 1
-            for (uint32_t jj = 0; jj < 4; ++jj) {
-              uint32_t m = Y.hits(d[jj]);
-              while (m) {
-                const uint32_t bit = __ffs(m) - 1;
-                m &= m - 1;
-                ws_admit(A, ctl, s_pool, thr, T, wbase, Y.rank16(tid + j * kWsNT, jj, bit), Y.count(d[jj], bit));
+          for (uint32_t j = 0; j < kVecs; ++j)
+            n_hit += __popc(Y.hits(v[j].x)) + __popc(Y.hits(v[j].y)) + __popc(Y.hits(v[j].z)) + __popc(Y.hits(v[j].w));
+          if (n_hit) {
+            uint32_t at = atomicAdd(&s_ncand, n_hit);
+            if (at + n_hit <= kSmallCand) {
+#pragma unroll
+              for (uint32_t j = 0; j < kVecs; ++j) {
+                const uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                if (((d[0] | d[1] | d[2] | d[3]) & Y.pre) == 0) continue;
+#pragma unroll
+                for (uint32_t jj = 0; jj < 4; ++jj) {
+                  uint32_t m = Y.hits(d[jj]);
+                  while (m) {
+                    const uint32_t bit = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_cand[at++] = Y.rank16(tid + j * kWsNT, jj, bit) | (Y.count(d[jj], bit) << 16);
+                  }
+                }
               }
             }
           }
+          ws_barrier();
+          const uint32_t n_cand = s_ncand;
+          if (n_cand <= kSmallCand) {
+            for (uint32_t c2 = tid; c2 < n_cand; c2 += kWsNT) {
+              const uint32_t e2 = s_cand[c2];
+              ws_admit(A, ctl, s_pool, thr, T, wbase, e2 & 0xFFFFu, e2 >> 16);
+            }
+          } else {
+            // more counters at the bound than the list holds (a flood of ties): the list is dropped, every thread admits
+            // its own hits -- only keys that beat the threshold take room in the pool, so the passes shrink whatever ties
+            // lie behind the threshold's rank (wsweep_kernel's robust scan)
+#pragma unroll
+            for (uint32_t j = 0; j < kVecs; ++j) {       // (unrolled: a dynamic index would put the vectors in scratch)
+              const uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+              for (uint32_t jj = 0; jj < 4; ++jj) {
+                uint32_t m = Y.hits(d[jj]);
+                while (m) {
+                  const uint32_t bit = __ffs(m) - 1;
+                  m &= m - 1;
+                  ws_admit(A, ctl, s_pool, thr, T, wbase, Y.rank16(tid + j * kWsNT, jj, bit), Y.count(d[jj], bit));
+                }
+              }
+            }
+          }
+          ws_barrier();                                  // (everyone has read the list's length)
+          if (tid == 0) s_ncand = 0;
         }
         ws_barrier();
+        if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 7u);
         const uint32_t ov = ctl->overflow, pn = ctl->pool_n;
         if (!(ov || pn > sel_at || (thr == kKeyInf && pn >= keep))) break;
         ws_barrier();                                    // (everyone has read the pool's state)
@@ -3243,6 +3346,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
     }
 #undef SMALL_LOAD_HEAD
     // ---- emit: best `keep` in final order
+    if (wid == 0) TRACE_MARK_AT(A, 50000u, q, 7u, 0u, 1u);
     ws_barrier();
     ws_compact_pool(s_pool, ctl, keep, n_sorted);
     const uint32_t nres = ctl->pool_n;
@@ -3258,7 +3362,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
     }
     if (tid == 0) A.counts[q] = nres;
     ws_barrier();                                        // pool reads done before the next needle resets it
+    if (wid == 0) TRACE_MARK_AT(A, 50000u, q, 7u, 0u, 2u);
   }
+#undef SMALL_ADVANCE
   if (STATS(A) && lane == 0) {
     atomicAdd(&STATS(A)[kStatPostingEntries], static_cast<unsigned long long>(st_ent));
     atomicAdd(&STATS(A)[kStatTableWords], static_cast<unsigned long long>(st_tab));

@@ -218,7 +218,7 @@ class RawMap:
     # bits of find_path_flags() (csrc/find_kernels.h: kPath*)
     PATH_FLAGS = ("nibble", "byte", "cold_start", "resweep", "compaction", "skipped", "ring_overflow", "pipelined",
                   "wide", "chunked", "ranged", "multi_pass", "tombstone", "own_only", "ws_task", "ws_left_out",
-                  "ws_robust", "ws_cand_overflow", "ws_pool_overflow", "ws_wide", "ws_table_walk", "nm_left_out")
+                  "ws_robust", "ws_cand_overflow", "ws_pool_overflow", "ws_wide", "ws_table_walk", "nm_left_out", "small")
 
     def find_path_flags(self, n):
         """Per needle of the last find call made while set_stats(True): which kernel paths its find took
