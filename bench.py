@@ -134,6 +134,8 @@ def build_haystack(name, scale, static_choice=False, force_sweep=0):
     m = RawMap()
     if static_choice or force_sweep:
         m.set_option("ws_autotune", 0)
+    if force_sweep in (1, 2, 3):
+        m.set_option("small_sweep", 0)
     if force_sweep == 1:                                # needle-major, nothing left out
         m.set_option("wsweep", 0); m.set_option("nm_cmin", 0)
     elif force_sweep == 2:                              # window-major
@@ -366,7 +368,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     algo_bytes = 8 * sum_nb + 8 * sum_T + 12 * sum_rows + 4 * n_q            # SURVEY.md 8(d), one launch
     k_ms = float(np.mean(kernel_ms))
     sweeps = {0: "latency mode / long needles only", 1: "needle-major", 2: "window-major",
-              3: "needle-major, dense slices left out of the count"}
+              3: "needle-major, dense slices left out of the count",
+              4: "small haystack: four waves and one window's counters per needle"}
     sweep = sweeps[m.get_option("last_sweep")]                               # of the timed launches
     # one more launch, untimed, with the kernels' own request counters on: the physical bytes and the
     # LDS-atomic lanes of exactly this batch -- by the SAME sweep (a measured choice is kept while counting)
@@ -509,7 +512,9 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "kernel_source_hash": kernel_source_hash(),
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
                            else "find_kernel<uint8_t,1024,false,true,true> (manager + workers; slices left out, settled by bitmap)"
-                           if sweep.startswith("needle-major, dense") else "find_kernel<uint8_t,1024,false,true,false>"),
+                           if sweep.startswith("needle-major, dense")
+                           else "find_small_kernel (+ find_kernel<uint8_t,1024,false,true,false> for needles of 16..64 trigrams)"
+                           if sweep.startswith("small") else "find_kernel<uint8_t,1024,false,true,false>"),
                 "sweep": sweep, "counted_sweep": counted_sweep, "sweep_measured": tuned,
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -576,7 +581,7 @@ def main():
                          "the N ranks' needles in one call; no torch.distributed")
     ap.add_argument("--inject-failure", default=None, metavar="WORKLOAD",
                     help="(tests) make that workload's cpu_baseline leg raise: the line must carry the error and the exit status be 1")
-    ap.add_argument("--force-sweep", type=int, default=0, choices=(0, 1, 2, 3),
+    ap.add_argument("--force-sweep", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="1 needle-major, 2 window-major, 3 needle-major with slices left out: that sweep whatever a "
                          "measurement would say (PMC passes of the sweep a bench run chose: tools/collect_profiles.sh)")
     ap.add_argument("--static-choice", action="store_true",

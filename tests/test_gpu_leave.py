@@ -21,7 +21,7 @@ LEFT_OUT = 1 << 21            # kPathNmLeftOut
 def _pair(hay, off, **opts):
     n = len(off) - 1
     m, o = RawMap(), Oracle()
-    for k, v in dict(ws_autotune=0, wsweep=0, nm_min_windows=0, **opts).items():
+    for k, v in dict(ws_autotune=0, wsweep=0, nm_min_windows=0, small_sweep=0, **opts).items():
         m.set_option(k, v)
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     o.put_many(hay, off)

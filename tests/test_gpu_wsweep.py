@@ -25,6 +25,7 @@ def _ws(m, **kw):
     kw.setdefault("ws_min_slice", 0)                           # whatever the haystack's slice sizes
     kw.setdefault("ws_static_slice", 0)
     kw.setdefault("ws_autotune", 0)                            # ... and without measuring: the sweep it is
+    kw.setdefault("small_sweep", 0)                            # (small images have a sweep of their own: tests/test_gpu_small.py)
     for k, v in kw.items():
         m.set_option(k, v)
 
@@ -32,6 +33,7 @@ def _ws(m, **kw):
 def _pair(hay, off):
     n = len(off) - 1
     m, o = RawMap(), Oracle()
+    m.set_option("small_sweep", 0)                 # (small images: this file is about the window-major sweep and the choice)
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     o.put_many(hay, off)
     return m, o

@@ -24,7 +24,7 @@ sweep_of() { python - "$out/bench.json" "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); wl = sys.argv[2]
 r = (d if wl == "geonames" else d["extra_configs"][wl])["roofline"]["sweep"]
-print(3 if r.startswith("needle-major, dense") else 2 if r.startswith("window") else 1)
+print(3 if r.startswith("needle-major, dense") else 2 if r.startswith("window") else 4 if r.startswith("small") else 1)
 PY
 }
 for wl in geonames words skewed geonames_x4 geonames_miss; do
