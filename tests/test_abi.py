@@ -68,10 +68,12 @@ def test_the_library_never_reads_the_environment():
     import subprocess
     out = subprocess.run(["nm", "-D", "--undefined-only", _native.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True)
     assert not re.search(r"\b(secure_)?getenv\b", out.stdout)
-    # ... and the kernel source carries one build switch (the counted build), no experiment switches
+    # ... and the kernel source carries two build switches and no experiment switches: the counted build, and the TRACE
+    # build of the timed kernels (shader-clock stamps of a few needles' steps for tools/trace_steps.py; it compiles to
+    # nothing in the library that ships)
     src = open(os.path.join(ROOT, "blurrily_amd", "csrc", "find_kernels.hip")).read()
     switches = set(re.findall(r"^#\s*if(?:n?def)?\s+!?\s*(?:defined\s*\(\s*)?(\w+)", src, flags=re.M))
-    assert switches == {"BLURRILY_COUNTED"}, switches
+    assert switches == {"BLURRILY_COUNTED", "BLURRILY_TRACE"}, switches
 
 
 def test_options_set_and_get():
@@ -80,7 +82,8 @@ def test_options_set_and_get():
     m = RawMap()
     defaults = {"wsweep": 1, "ws_cmin": 3, "ws_min_windows": 8, "ws_min_needles": 16384, "dense_min": 1024,
                 "ws_min_slice": 1550, "ws_autotune": 1, "ws_static_slice": 2200, "ws_choice": 0, "host_chunk": 131072,
-                "nm_cmin": 3, "nm_dense": 4096, "nm_min_windows": 256, "devices": 1, "last_sweep": 0}
+                "nm_cmin": 3, "nm_dense": 4096, "nm_min_windows": 256, "devices": 1, "last_sweep": 0, "small_sweep": 1,
+                "small_min_needles": 4096}
     for k, v in defaults.items():
         assert m.get_option(k) == v, k
     m.set_option("ws_cmin", 2)
