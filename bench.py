@@ -509,6 +509,12 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "hbm_only_frac": None,
                 "hbm_only_note": "no DRAM-only byte counter on gfx950 (TCC_EA0_RDREQ_DRAM = requests destined for DRAM, "
                                  "counted before the Infinity Cache); see bound_scope and extra_configs.geonames_x4",
+                # what the dominant kernel waits for when `frac` is well below 1: a needle's sweep is
+                # a chain of steps -- count, barrier, scan, barrier -- of ~4 us each whatever they read, two (small images:
+                # four) chains per CU because of the counters' LDS; the bytes are what the steps move, not what binds them
+                "bound_note": "hbm is the roofline this integer gather/count path is held against; below ~0.5 of it the "
+                              "kernel is bound by its per-step chain (barriers, LDS round trips, one global latency), "
+                              "see DESIGN.md section 5 and profiles/r04_step_timeline.md",
                 "kernel_source_hash": kernel_source_hash(),
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
                            else "find_kernel<uint8_t,1024,false,true,true> (manager + workers; slices left out, settled by bitmap)"
