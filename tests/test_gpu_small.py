@@ -3,6 +3,8 @@ An image of at most eight windows serves large batches at limits up to 64 with f
 counters per needle; needles of 16..64 distinct trigrams are listed by it and follow through the byte-counter kernel.
 What it must compute is what every sweep must (storage.c:477-580): every reference's match count, the best `limit`
 by matches, weight, reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -124,4 +126,54 @@ def test_tombstones_and_pending_puts_under_the_small_sweep():
         assert m.put(s + b"x", 900000 + k, 0) == o.put(s + b"x", 900000 + k, 0)
     _check(m, o, q, qo, 10)
     assert m.device_info()["base_builds"] == 1
+    m.close()
+
+
+_FUZZ_FIRST = int(os.environ.get("BLURRILY_FUZZ_FIRST", "0"))           # soak runs: BLURRILY_FUZZ_FIRST=4 BLURRILY_FUZZ_SEEDS=40
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("BLURRILY_FUZZ_SEEDS", "4"))))
+def test_randomised_small_images_both_new_sweeps(seed):
+    """Seeded sweep over small images (one to eight windows) and batches large enough for the small-haystack sweep: the
+    three generators, custom weights (ranks then do not follow length), sparse references, deletes before the first
+    find (tombstones: no cold start) and puts after it (the delta image), any limit up to 64 -- and the same batch
+    through the needle-major sweep that leaves slices out, forced, at limits up to 149."""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([900, 30000, 120000, 300000, 500000]))
+    gen = [lambda: W.geonames(n, max(500, n // 12), 150 + seed), lambda: W.words(n, 160 + seed),
+           lambda: W.skewed(n, 170 + seed)][seed % 3]
+    hay, off = gen()
+    n = len(off) - 1
+    refs = (np.sort(rng.choice(2**31 - 2, size=n, replace=False)) + 1).astype(np.uint32) if seed % 2 else \
+        np.arange(1, n + 1, dtype=np.uint32)
+    weights = None
+    if seed % 4 >= 2:
+        weights = rng.integers(0, 40, size=n).astype(np.uint32)
+        weights[rng.random(n) < 0.3] = 0
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(hay, off, refs, weights)
+    if weights is None:
+        o.put_many(hay, off, refs)
+    else:
+        for s_, r_, w_ in zip(W.unpack(hay, off), refs.tolist(), weights.tolist()):
+            o.put(s_, r_, w_)
+    if seed % 3 == 0:
+        for r in rng.choice(refs, size=min(150, n // 4), replace=False).tolist():
+            assert m.delete(r) == o.delete(r)
+    q, qo = _mixed(hay, off, 4500, 180 + seed)
+    limit = int(rng.choice([1, 5, 10, 33, 64]))
+    _check(m, o, q, qo, limit)
+    m.put(b"an entirely new entry", 2**31 - 1, 0); o.put(b"an entirely new entry", 2**31 - 1, 0)
+    _check(m, o, q, qo, limit)
+    # the same batch through the sweep that leaves slices out (forced; small "nm_dense": there are dense slices to leave)
+    for k, v in dict(small_sweep=0, ws_autotune=0, wsweep=0, nm_min_windows=0, nm_cmin=int(rng.integers(1, 5)),
+                     nm_dense=int(rng.choice([128, 512, 2048])), dense_min=128).items():
+        m.set_option(k, v)
+    limit2 = int(rng.choice([10, 64, 100, 149]))
+    rows, counts = m.find_batch_packed(q, qo, limit2)
+    assert m.get_option("last_sweep") == 3
+    want = o.batch(q, qo, limit=limit2)
+    assert np.array_equal(counts, want["counts"])
+    live = np.arange(limit2)[None, :] < counts[:, None].astype(np.int64)
+    assert np.array_equal(np.where(live[:, :, None], rows, 0), np.where(live[:, :, None], want["rows"], 0))
     m.close()
