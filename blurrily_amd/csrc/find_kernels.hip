@@ -3080,7 +3080,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];
   __shared__ unsigned long long s_pool[kWsPool];
   __shared__ Control s_ctl;
-  __shared__ uint32_t s_tally[4];                        // the cold start's tallies, one per pass of the bisection
+  __shared__ uint32_t s_tally[8];                        // the cold start's tallies, one per pass of the search
   __shared__ uint32_t s_nextq;
   __shared__ uint32_t s_cand[kSmallCand];                // a window's counters at the bound: in-window rank | count << 16
   __shared__ uint32_t s_ncand;                           // the queue slot popped for the needle after the current one
@@ -3091,7 +3091,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   const uint32_t sel_at = min(keep + max(6u, keep / 2), kWsPool / 2);
   constexpr uint32_t kVecs = kWsCntWords / 4 / kWsNT;    // a thread's vectors of the window's counters: eight
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
-  if (tid < 4) s_tally[tid] = 0;
+  if (tid < 8) s_tally[tid] = 0;
   if (tid == 0) s_ncand = 0;
   uint32_t st_ent = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0, st_tab = 0;
   ws_barrier();
@@ -3244,7 +3244,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
           PATH_FLAG(A, q, kPathColdStart);
           uint32_t lo = 1, hi = min(T, 15u), pass = 0;
           while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1) >> 1;
+            // (upward from 2 first -- the bound of a first window is 2 or 3 for most needles: two or three passes where
+            // a bisection of 1..15 always takes four --, a bisection of what is left from 4 on: seven passes at most)
+            const uint32_t mid = lo < 4 ? lo + 1 : (lo + hi + 1) >> 1;
             const WsLayout<false> Y(mid, 0u, wlen);
             uint32_t mine = 0;
 #pragma unroll
@@ -3255,10 +3257,10 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
             if (lane == 0 && mine) atomicAdd(&s_tally[pass], mine);
             ws_barrier();
             if (s_tally[pass] >= keep) lo = mid; else hi = mid - 1;
-            ++pass;                                      // (at most four passes: hi <= 15)
+            ++pass;
           }
           ws_barrier();                                  // everyone has read the last tally
-          if (tid < 4) s_tally[tid] = 0;
+          if (tid < 8) s_tally[tid] = 0;
           floor_need = max(floor_need, lo);
         }
         if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 6u);
@@ -3270,8 +3272,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
           const WsLayout<false> Y(min(floor_need, 16u), 0u, wlen);
           uint32_t n_hit = 0;
 #pragma unroll
-          for (uint32_t j = 0; j < kVecs; ++j)
-            n_hit += __popc(Y.hits(v[j].x)) + __popc(Y.hits(v[j].y)) + __popc(Y.hits(v[j].z)) + __popc(Y.hits(v[j].w));
+          for (uint32_t j = 0; j < kVecs; ++j)           // (one AND per vector first: with a threshold most hold nothing at the bound)
+            if (((v[j].x | v[j].y | v[j].z | v[j].w) & Y.pre) != 0)
+              n_hit += __popc(Y.hits(v[j].x)) + __popc(Y.hits(v[j].y)) + __popc(Y.hits(v[j].z)) + __popc(Y.hits(v[j].w));
           if (n_hit) {
             uint32_t at = atomicAdd(&s_ncand, n_hit);
             if (at + n_hit <= kSmallCand) {
