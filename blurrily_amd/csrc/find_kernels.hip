@@ -3075,6 +3075,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void wsweep_kernel(const FindArg
 // needles with at most 15 distinct trigrams (4 bits suffice whatever the window); the others are listed for the
 // byte-counter launch that follows (FindArgs::over_list).  Same answer by construction: every posting counted, every
 // counter held against the exact threshold, any window order.
+// (Measured and left out: eight waves per needle instead of four -- 512 threads, 64 VGPRs, 69 of them spilled -- 3.5 -> 4.2 ms
+// per 100 k needles at configs[1]; a third unit loaded a window ahead -- the kernel sits at 128 VGPRs: 12 spilled -- 3.6 -> 3.7 ms.)
 constexpr uint32_t kSmallCand = 1024;
 __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const FindArgs A) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWsCntWords + 4];
