@@ -1940,7 +1940,11 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       if constexpr (MANAGER) {
         if (left == kLeftDone) BLURRILY_PEND_SETTLE((e & 1u) ^ 1u, (e - 1u) & 3u, p_prev, ls_prev);
         if (left == kLeftSelect && !own_pending && lane == 0) ctl->pend_n[s] = 0;
-        p_prev = p; ls_prev = 0;
+        // (the step's own pending candidates, where it was not swept again, stay on their list: the next step's scan phase
+        // settles them like any step's -- the compaction below empties the pool's tail first, so they have their room.
+        // Settling them here, synchronously, was a global round trip with sixteen waves waiting, at every other compaction.)
+        p_prev = p; ls_prev = own_pending ? hy_ >> 24 : 0u;
+        if (!ranked && have_thr && left != kLeftDone) BLURRILY_RANK();   // (the others are at the barrier: off the next step's count phase)
       }
       __syncthreads();
     }
@@ -1961,10 +1965,6 @@ __device__ __forceinline__ void sweep_role(const FindArgs& A, const Needle& nd, 
       ++st_redo;                                                // pool overflow: sweep step p again -- every slice of it
       if ((hy_ >> 24) != 0) BLURRILY_COUNT_WALK(p);             // (the published table lists no units of left-out slices)
       else if constexpr (!MANAGER) BLURRILY_COUNT_UNITS(s, n_units, false);
-      __syncthreads();
-    }
-    if (own_pending) {
-      if constexpr (MANAGER) BLURRILY_PEND_SETTLE(s, e & 3u, p, hy_ >> 24);
       __syncthreads();
     }
     thr_c = ctl->thr;
