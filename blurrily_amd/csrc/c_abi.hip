@@ -139,6 +139,17 @@ struct trigram_map_t {
   hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer ws_codes, ws_small, ws_parts, ws_io_in, ws_io_out;
   unsigned char* h_stage = nullptr;     // pinned host staging: [kStageBytes in | kStageBytes out]
+  // the single find's own launch (find_one): a stream, host-coherent pinned memory the kernel writes rows, count and a
+  // sequence word into, the per-workgroup lists and the ticket on the device
+  struct One {
+    hipStream_t    stream = nullptr;
+    unsigned char* h_out = nullptr;     // [kOneMaxKeep rows | count | sequence word]
+    unsigned char* d_out = nullptr;     // the same memory as the device addresses it
+    DeviceBuffer   d_parts;             // [kOneMaxGrid * kOneMaxKeep keys | kOneMaxGrid flags]
+    uint32_t       seq = 0;
+    bool           enabled = true;      // option "one_launch"
+    uint64_t       taken = 0;           // finds served this way (option "one_taken", read-only)
+  } one;
   // large host-buffer batches go in chunks through a three-stream pipeline (find_batch_chunked)
   uint32_t    host_chunk = 131072;      // needles per chunk (option "host_chunk"; 0: never chunk)
   struct Pipe {
@@ -832,6 +843,9 @@ int blurrily_storage_close(trigram_map* haystack) {
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
     m->ws_io_out.release(); m->ws_tomb.release(); m->ws_flags.release();
     if (m->h_stage) (void)hipHostFree(m->h_stage);
+    if (m->one.stream) { (void)hipStreamSynchronize(m->one.stream); (void)hipStreamDestroy(m->one.stream); }
+    if (m->one.h_out) (void)hipHostFree(m->one.h_out);
+    m->one.d_parts.release();
     for (int i = 0; i < 2; ++i) {
       if (m->pipe.h_in[i]) (void)hipHostFree(m->pipe.h_in[i]);
       if (m->pipe.h_out[i]) (void)hipHostFree(m->pipe.h_out[i]);
@@ -1124,6 +1138,86 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
   return 0;
 }
 
+// ---- ONE needle, the caller waiting: one launch, no copies (find_kernels.hip: find_one_kernel) ---------------------
+// The reference's only call shape (ext/blurrily/map_ext.c:131-162 -> storage.c:477-580).  Returns the number of rows,
+// -1 with errno, or kOneNotTaken when the find has to go the batch's way: a limit of 0 or above kOneMaxKeep, a needle
+// of more than 64 distinct trigrams, mutations the base image does not hold yet (tombstones, pending puts), timing or
+// request counters switched on, option "one_launch" 0.
+constexpr int kOneNotTaken = -2;
+constexpr size_t kOneHostBytes = kOneMaxKeep * sizeof(trigram_match_t) + 64;
+
+static int find_one(trigram_map m, const char* needle, uint16_t limit, trigram_match results) {
+  if (!m->one.enabled || limit == 0 || limit > kOneMaxKeep || m->timing || m->collect_stats) return kOneNotTaken;
+  const size_t len = std::strlen(needle);
+  if (len > 255) return kOneNotTaken;
+  uint16_t codes[256];
+  const int T = tokenise(needle, len, codes);             // tokeniser.c:59-119
+  if (T > 64) return kOneNotTaken;
+  DeviceScope scope(m->dev.device);
+  // what the reference's find does first: sort the needle's dirty buckets (storage.c:516), sum their sizes (:498-503)
+  if (m->host->dirty_buckets())
+    for (int k = 0; k < T; ++k) m->host->sort_bucket_if_dirty(codes[k]);
+  if (ensure_device(m) < 0) return -1;
+  if (!log_empty(m)) return kOneNotTaken;
+  uint64_t nb = 0;
+  for (int k = 0; k < T; ++k) nb += m->host->bucket(codes[k]).used;
+  if (nb == 0) return 0;                                  // storage.c:503
+  auto& O = m->one;
+  if (!O.stream) {
+    BLURRILY_HIP_TRY(hipStreamCreateWithFlags(&O.stream, hipStreamNonBlocking));
+    BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&O.h_out), kOneHostBytes,
+                                   hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(O.h_out, 0, kOneHostBytes);
+    BLURRILY_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&O.d_out), O.h_out, 0));
+  }
+  const size_t key_bytes = size_t(kOneMaxGrid) * kOneMaxKeep * 8;
+  if (!O.d_parts.p) {
+    if (O.d_parts.reserve(key_bytes + kOneMaxGrid * 4, O.stream) < 0) return -1;
+    BLURRILY_HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(O.d_parts.p) + key_bytes, 0, kOneMaxGrid * 4, O.stream));
+  }
+  const DeviceIndex& ix = m->dev;
+  FindArgs a{};
+  a.slice_se = ix.d_slice_se; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
+  a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
+  a.win_max_tri = ix.d_win_max_tri; a.nib_windows = ix.nib_windows; a.dense_min8 = ix.dense_min8;
+  a.limit = limit; a.keep = limit; a.pool_cap = 512;
+#ifdef BLURRILY_TRACE
+  if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
+  a.phase_clocks = m->d_phase;                         // (trace build: find_one_kernel's wall-clock marks, 16 per workgroup)
+#endif
+  // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond
+  uint32_t per = 1;
+  if (ix.n_windows > kOneMaxGrid) { per = (ix.n_windows + kOneMaxGrid - 1) / kOneMaxGrid; per += per & 1u; }
+  const uint32_t grid = (ix.n_windows + per - 1) / per;
+  unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p);
+  const uint32_t seq = ++O.seq ? O.seq : ++O.seq;         // (never 0: what the word holds before the first find)
+  volatile uint32_t* h_words = reinterpret_cast<volatile uint32_t*>(O.h_out + kOneMaxKeep * sizeof(trigram_match_t));
+  if (launch_find_one(a, codes, uint32_t(T), per, grid, reinterpret_cast<unsigned long long*>(dp),
+                      reinterpret_cast<uint32_t*>(dp + key_bytes),
+                      reinterpret_cast<trigram_match_t*>(O.d_out),
+                      reinterpret_cast<uint32_t*>(O.d_out + kOneMaxKeep * sizeof(trigram_match_t)), seq, O.stream) < 0)
+    return -1;
+  // The kernel's last store is the sequence word; the host polls it in the pinned page instead of waiting for the
+  // runtime to notice the kernel's completion signal (an interrupt or a slower poll: 10 us and more).
+  uint64_t spins = 0;
+  while (h_words[1] != seq) {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((++spins & 0xFFFFFu) == 0) {                      // every few milliseconds: is the stream still alive?
+      const hipError_t q = hipStreamQuery(O.stream);
+      if (q == hipSuccess && h_words[1] != seq) { std::fprintf(stderr, "blurrily_hip: find_one finished without its rows\n"); errno = EIO; return -1; }
+      if (q != hipSuccess && q != hipErrorNotReady) { std::fprintf(stderr, "blurrily_hip: find_one: %s\n", hipGetErrorString(q)); errno = EIO; return -1; }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const uint32_t n_rows = h_words[0];
+  const uint32_t count = n_rows < limit ? n_rows : uint32_t(limit);
+  std::memcpy(results, O.h_out, size_t(count) * sizeof(trigram_match_t));
+  ++O.taken;
+  return int(count);
+}
+
 extern "C" {
 
 int blurrily_storage_find_batch(trigram_map m, const char* packed, const uint64_t* offsets, size_t n,
@@ -1150,6 +1244,8 @@ int blurrily_normalize_batch_device(const char* d_packed, const uint64_t* d_offs
 }
 
 int blurrily_storage_find(trigram_map haystack, const char* needle, uint16_t limit, trigram_match results) {
+  const int one = find_one(haystack, needle, limit, results);
+  if (one != kOneNotTaken) return one;
   const uint64_t offsets[2] = {0, std::strlen(needle)};
   uint32_t count = 0;
   // the device writes `limit` rows per needle; go through a scratch so a short
@@ -1227,7 +1323,8 @@ constexpr OptionSlot kMapOptions[] = {
     {"ws_autotune", 0, 1}, {"ws_static_slice", 0, 1ll << 31}, {"ws_choice", 0, 0},
     {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64},
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
-    {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32}};
+    {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
+    {"one_launch", 0, 1}, {"one_taken", 0, 0}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1268,6 +1365,8 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 15: case 16: case 17: case 18: return 0;        // (read-only: what the last measurement saw)
     case 19: m->small_sweep = value != 0; break;
     case 20: m->small_min_needles = uint32_t(std::min<long long>(value, 0xFFFFFFFFll)); break;
+    case 21: m->one.enabled = value != 0; return 0;      // (the single find's own launch; nothing to measure again)
+    case 22: return 0;                                   // (read-only)
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1308,6 +1407,8 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
       return 0;
     case 19: *value = m->small_sweep; return 0;
     case 20: *value = m->small_min_needles; return 0;
+    case 21: *value = m->one.enabled; return 0;
+    case 22: *value = (long long)m->one.taken; return 0;
     default: errno = EINVAL; return -1;
   }
 }
@@ -1338,6 +1439,42 @@ int blurrily_storage_find_path_flags(trigram_map m, uint32_t* out, size_t n) {
   BLURRILY_HIP_TRY(hipMemcpy(out, m->ws_flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return 0;
 }
+
+#ifdef BLURRILY_TRACE
+// debugging aid, trace build only (tools/touch_map.py): first-touch latency of a kernel's loads over the postings
+// array -- workgroup g loads `chunk` bytes at g * (bytes / n) of d_ent and notes the device's 100 MHz wall clock around
+// it: out[2 g] = start, out[2 g + 1] = duration, in 10 ns ticks
+namespace {
+__global__ __launch_bounds__(256) void touch_map_kernel(const unsigned char* base, size_t stride, uint32_t chunk16, unsigned long long* out) {
+  const unsigned long long t0 = wall_clock64();
+  const uint4* p = reinterpret_cast<const uint4*>(base + size_t(blockIdx.x) * stride);
+  uint32_t acc = 0;
+  for (uint32_t i = threadIdx.x; i < chunk16; i += 256) { const uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+  __shared__ uint32_t s_acc;
+  if (threadIdx.x == 0) s_acc = 0;
+  __syncthreads();
+  atomicAdd(&s_acc, acc);
+  __syncthreads();
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = t0 + (s_acc == 0x12345678u ? 1 : 0); out[2 * blockIdx.x + 1] = t1 - t0; }
+}
+}  // namespace
+int blurrily_debug_touch_map(trigram_map m, unsigned long long* out, uint32_t n, uint32_t chunk_bytes, int which) {
+  DeviceScope scope(m->dev.device);
+  unsigned long long* d_out = nullptr;
+  BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), size_t(n) * 16));
+  const unsigned char* base = which == 0 ? reinterpret_cast<const unsigned char*>(m->dev.d_ent)
+                                         : reinterpret_cast<const unsigned char*>(m->dev.d_slice_se);
+  const size_t bytes = which == 0 ? size_t(m->dev.n_slots) * 2 : size_t(m->dev.n_windows) * kNumCodes * 8;
+  const size_t stride = ((bytes - chunk_bytes) / n) & ~size_t(15);
+  hipLaunchKernelGGL(touch_map_kernel, dim3(n), dim3(256), 0, nullptr, base, stride, chunk_bytes / 16, d_out);
+  BLURRILY_HIP_TRY(hipDeviceSynchronize());
+  BLURRILY_HIP_TRY(hipMemcpy(out, d_out, size_t(n) * 16, hipMemcpyDeviceToHost));
+  (void)hipFree(d_out);
+  std::fprintf(stderr, "touch_map: base %p, %zu bytes, stride %zu\n", static_cast<const void*>(base), bytes, stride);
+  return 0;
+}
+#endif
 
 // debugging aid (tools/phase_profile.py): per-workgroup phase clocks of the last find launched while
 // blurrily_storage_set_stats was on

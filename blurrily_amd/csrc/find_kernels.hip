@@ -73,9 +73,12 @@
 #define TRACE_MARK_AT(A, base_, q_, e_, role_, mark_) do { if ((A).phase_clocks && (q_) - (base_) < 64u && (e_) < 64u) { \
     const unsigned long long t_ = clock64(); \
     if ((threadIdx.x & 63u) == 0) (A).phase_clocks[(((((q_) - (base_)) * 64u + (e_)) * 2u + (role_)) * 8u) + (mark_)] = t_; } } while (0)
+// find_one_kernel: the device's 100 MHz wall clock at mark i of workgroup blockIdx.x, phase_clocks[blockIdx.x * 16 + i]
+#define ONE_MARK(A, i_) do { if ((A).phase_clocks && threadIdx.x == 0) (A).phase_clocks[blockIdx.x * 16u + (i_)] = wall_clock64(); } while (0)
 #else
 #define TRACE_MARK(A, q_, e_, role_, mark_) do { } while (0)
 #define TRACE_MARK_AT(A, base_, q_, e_, role_, mark_) do { } while (0)
+#define ONE_MARK(A, i_) do { } while (0)
 #endif
 
 namespace blurrily {
@@ -3382,6 +3385,435 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   }
 }
 
+// ============================================================ one needle, now ==================
+// blurrily_storage_find -- the reference's only call shape (ext/blurrily/map_ext.c:131-162, bin/bench:93-95): ONE
+// needle, the caller waiting.  Through round 4 it went the batch's way: a staged copy in, tokenise_wave_kernel,
+// find_kernel in latency mode, merge_parts_small_kernel, a copy out, a stream synchronise -- six operations, each a
+// packet the command processor orders behind the one before (68 us at Geonames scale, 39 of them the find kernel's:
+// queue pop, needle scalars, codes, a learning sweep of the needle's own length class, then its own range).  Here it
+// is ONE launch and no copy:
+//   * the host tokenises (csrc/tokeniser.h: what put() runs) and passes the needle's codes AS KERNEL ARGUMENTS;
+//   * workgroup g owns windows [g * per, (g + 1) * per) -- one window each at Geonames scale, so every workgroup runs
+//     exactly ONE step: slice table (every wave its own copy, lane t = trigram t), the wave's units with four loads
+//     in flight (a workgroup is alone on its CU: 128 VGPRs), count, barrier, select -- no queue, no learning sweep,
+//     no ring;
+//   * SELECT takes a window's best `keep` counters EXACTLY, whatever ties it holds (one_select): every thread reads
+//     its four vectors of counters once; a bisection over the counter value IN REGISTERS finds the largest c that at
+//     least `keep` counters reach; counters above c enter the pool, and of the counters AT c only the lowest ranks
+//     that are still missing -- found by a prefix count in rank order (wave w owns a contiguous 4 KiB of counters).
+//     A window of thousands of identical strings -- thousands of counters tied at the bound, the common case of a
+//     needle made of popular words -- therefore costs what any window costs; admitting every tie, overflowing the
+//     pool and sweeping the window again (scan_window's way, made for a sweep that arrives with a threshold) took
+//     30 us in such windows, measured;
+//   * a workgroup leaves its best `keep` keys in global memory and sets its flag; the grid's LAST workgroup waits for
+//     the flags, loads all the lists at once, keeps the keys not above the keep-th smallest list head, sorts those few, looks the
+//     references and weights up and writes rows, count and a sequence word straight into host-coherent pinned
+//     memory, where the host thread is polling.
+// Same answer by construction: every posting of every window counted, a window's best `keep` candidates that beat the
+// workgroup's threshold taken exactly, the best `keep` of the union of per-workgroup best `keep` lists (nothing can be
+// lost).  Served: needles of at most 64 distinct trigrams, limits up to kOneMaxKeep, images without tombstones or
+// pending puts (c_abi.hip: find_one); everything else goes the batch's way as before.
+constexpr uint32_t kOnePool = 512;
+constexpr int      kOneThreads = 1024;                   // (512 -- eight waves, 256 VGPRs each -- measured: 35.4 against 33.5 us)
+constexpr uint32_t kOneAhead = 4;                        // units a wave loads before it counts the first of them
+
+// this wave's units of one step: lane t holds trigram t's slice of the step's (even) window (a0, b0) and, with 4-bit
+// counters, of the odd one (a1, b1); unit k of the step belongs to wave k mod 16
+template <typename CT, int NT>
+__device__ __forceinline__ void one_count(const uint16_t* __restrict__ ent, uint32_t* cnt32, const uint32_t a0,
+                                          const uint32_t b0, const uint32_t a1, const uint32_t b1, const uint32_t wid,
+                                          const uint32_t lane) {
+  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  constexpr uint32_t kNW = NT / 64;
+  const uint32_t units0 = slice_units(a0, b0), units1 = kNib ? slice_units(a1, b1) : 0u;
+  const uint32_t incl = wave_inclusive_sum(units0 + units1);
+  const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+  const uint32_t excl = incl - units0 - units1;
+  for (uint32_t k0 = wid; k0 < total; k0 += kOneAhead * kNW) {
+    uint4 v[kOneAhead];
+    uint32_t half[kOneAhead];
+#pragma unroll
+    for (uint32_t i = 0; i < kOneAhead; ++i) {
+      const uint32_t k = k0 + i * kNW;
+      v[i] = make_uint4(kPadPair, kPadPair, kPadPair, kPadPair);
+      half[i] = 0;
+      if (k < total) {                                   // (uniform)
+        const uint32_t t = uint32_t(__builtin_ctzll(__ballot(incl > k)));
+        const uint32_t ji = k - __builtin_amdgcn_readlane(excl, t), u0 = __builtin_amdgcn_readlane(units0, t);
+        const bool odd = ji >= u0;
+        const uint32_t start = odd ? __builtin_amdgcn_readlane(a1, t) + (ji - u0) * 512u
+                                   : __builtin_amdgcn_readlane(a0, t) + ji * 512u;
+        const uint32_t end = odd ? __builtin_amdgcn_readlane(b1, t) : __builtin_amdgcn_readlane(b0, t);
+        half[i] = odd ? 1u : 0u;
+        v[i] = load_group(ent, start + lane * 8, end);
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kOneAhead; ++i) bump_unit<CT>(cnt32, v[i], half[i]);
+  }
+}
+
+// The window's counters are complete: take its best `keep` candidates that beat the threshold -- EXACTLY that many at
+// most, whatever ties there are -- into the pool, and clear the counters.  Wave w owns vectors [256 w, 256 w + 256) of
+// the 4 096 (lane l its j-th round's vector 256 w + 64 j + l: conflict-free reads, and (w, j, l) ascending is rank
+// ascending inside a window -- with 4-bit counters inside each of the pair's two windows, the even one's ranks first).
+struct OneShared {
+  uint32_t tally[12];           // the bisection's tallies, one per pass and bound
+  uint32_t above[16], tie0[16];  // per wave: counters above the bound, counters at it (even | odd window << 16, clamped)
+};
+template <typename CT, int NT>
+__device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, const uint32_t T, const uint32_t keep, Control* ctl,
+                                           unsigned long long* pool, OneShared* sh, const uint32_t wbase,
+                                           const uint32_t wlen) {
+  using S = ScanTraits<CT>;
+  using P = Packing<CT>;
+  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  (void)A;
+  constexpr uint32_t kNW = NT / 64, kR = S::kVecs / NT;      // rounds: a wave owns kR * 64 consecutive vectors
+  static_assert(S::kVecs == 4096 && kNW * kR * 64 == 4096 && kNW <= 16, "the waves share the 4 096 vectors evenly");
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t nvec = S::nvec(wlen);
+  uint4 v[kR];
+#pragma unroll
+  for (uint32_t j = 0; j < kR; ++j) {
+    const uint32_t i = (wid * kR + j) * 64 + lane;
+    v[j] = make_uint4(0, 0, 0, 0);
+    if (i < nvec) v[j] = cnt128[i];
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kR; ++j) {                    // cleared at once: the rest works on the registers
+    const uint32_t i = (wid * kR + j) * 64 + lane;
+    if (i < nvec) cnt128[i] = make_uint4(0, 0, 0, 0);
+  }
+  S::clear_unreached_pad(cnt128, nvec, tid);
+  // counters of this thread that reach `bound`
+  auto reach = [&](const uint32_t bound) {
+    const typename S::Need nq = S::prepare(bound);
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kR; ++j)
+      n += __popc(S::hits(v[j].x, nq)) + __popc(S::hits(v[j].y, nq)) + __popc(S::hits(v[j].z, nq)) + __popc(S::hits(v[j].w, nq));
+    return n;
+  };
+  uint32_t pass = 0;
+  auto tally = [&](const uint32_t bound) {               // the workgroup's counters that reach `bound` (one barrier)
+    const uint32_t incl = wave_inclusive_sum(reach(bound));
+    if (lane == 63 && incl) atomicAdd(&sh->tally[pass], incl);
+    __syncthreads();
+    return sh->tally[pass++];
+  };
+  // the bound a counter has to reach to beat the threshold (1: no threshold yet); c: the largest value >= that bound
+  // which at least `keep` counters reach -- or the bound itself, with fewer reaching it: then all of them are taken
+  const unsigned long long thr = ctl->thr;
+  const uint32_t cap = min(T, S::kMaxCount);
+  uint32_t lo = matches_needed(thr, T, wbase), hi = cap;
+  bool all = false;
+  if (lo > cap) {
+    all = true; lo = cap + 1;                            // nothing of this window can enter
+  } else if (tally(lo) < keep) {
+    all = true;
+  } else {
+    while (lo < hi) {                                    // (at most seven passes with byte counters, four with 4-bit ones)
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (tally(mid) >= keep) lo = mid; else hi = mid - 1;
+    }
+  }
+  const uint32_t c = lo;
+  ONE_MARK(A, 6);
+  // per lane and round: counters above c, counters AT c in the even / odd window
+  const typename S::Need at_c = S::prepare(min(c, cap)), above_c = S::prepare(min(c + 1, S::kMaxCount));
+  const bool has_above = c + 1 <= cap, none = c > cap;
+  constexpr uint32_t kEven = kNib ? 0x08080808u : 0x80808080u, kOdd = kNib ? 0x80808080u : 0u;   // a field's top bit, by window of the pair
+  auto masks = [&](const uint32_t wv, uint32_t& up, uint32_t& tie) {
+    const uint32_t r = none ? 0u : S::hits(wv, at_c);
+    up = has_above ? S::hits(wv, above_c) : 0u;
+    tie = all ? 0u : r & ~up;
+    if (all) up = r;                                     // (fewer than keep reach the bound: every one of them is taken)
+  };
+  // per lane and round j: ties of the even window in bits 15:0, of the odd one in bits 31:16 (at most 16 each: one
+  // inclusive sum serves both); whether the round holds anything above the bound: bit j of up_rounds
+  uint32_t n_up = 0, up_rounds = 0, nt[kR];
+#pragma unroll
+  for (uint32_t j = 0; j < kR; ++j) {
+    const uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+    uint32_t ups = 0;
+    nt[j] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      uint32_t up, tie;
+      masks(d[k], up, tie);
+      ups += __popc(up);
+      nt[j] += __popc(tie & kEven) + (kNib ? __popc(tie & kOdd) << 16 : 0u);
+    }
+    n_up += ups;
+    up_rounds |= ups ? 1u << j : 0u;
+  }
+  uint32_t in[kR];                                      // inclusive sums over the lanes, per round (both windows, packed)
+#pragma unroll
+  for (uint32_t j = 0; j < kR; ++j) in[j] = wave_inclusive_sum(nt[j]);
+  const uint32_t up_incl = wave_inclusive_sum(n_up);
+  if (lane == 63) {
+    // (a wave's ties: at most 4 096 per window; published clamped to 2 047 -- sixteen waves' sum then stays inside 16
+    // bits, and a clamped figure is still at least any quota, which is all a prefix has to tell)
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kR; ++j) tot += in[j];
+    sh->above[wid] = up_incl;
+    sh->tie0[wid] = min(tot & 0xFFFFu, 2047u) | (min(tot >> 16, 2047u) << 16);   // (a lane-63 figure: the wave's)
+  }
+  __syncthreads();
+  // what lies in front of this wave: lanes 0..15 hold the sixteen waves' figures
+  const uint32_t wa = lane < kNW ? sh->above[lane] : 0u, wt = lane < kNW ? sh->tie0[lane] : 0u;
+  const uint32_t ia = wave_inclusive_sum(wa), it = wave_inclusive_sum(wt);
+  const uint32_t n_above = __builtin_amdgcn_readlane(ia, kNW - 1), n_tie0 = __builtin_amdgcn_readlane(it, kNW - 1) & 0xFFFFu;
+  const uint32_t quota = all ? 0u : keep - min(keep, n_above);            // ties still wanted, lowest ranks first
+  const uint32_t front = __builtin_amdgcn_readlane(it, wid) - __builtin_amdgcn_readlane(wt, wid);   // ties in front of this wave, packed
+  uint32_t run0 = front & 0xFFFFu;                       // even-window ties in front of this wave
+  uint32_t run1 = n_tie0 + (front >> 16);                // odd-window ties: behind ALL even ones
+  auto admit = [&](const uint32_t cnt, const uint32_t rank) {
+    const unsigned long long key = (static_cast<unsigned long long>(T - cnt) << 32) | rank;
+    if (key <= thr) {                                    // (the bound came from the threshold's match count; its rank decides ties with it)
+      const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
+      if (at < kOnePool) pool[at] = key;                 // (at most keep + keep keys: never full)
+    }
+  };
+#pragma unroll
+  for (uint32_t j = 0; j < kR; ++j) {
+    const uint32_t i = (wid * kR + j) * 64 + lane;
+    const uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+    const uint32_t mine_ex = in[j] - nt[j];              // this lane's ties of the round come behind these (packed)
+    uint32_t at0 = run0 + (mine_ex & 0xFFFFu), at1 = run1 + (mine_ex >> 16);
+    const uint32_t round_tot = __builtin_amdgcn_readlane(in[j], 63);
+    run0 += round_tot & 0xFFFFu;
+    run1 += round_tot >> 16;
+    // (a lane with nothing above the bound and all of its ties behind the quota -- nearly every lane of a window of
+    // thousands of ties -- has nothing to admit)
+    if (!((up_rounds >> j) & 1u) && !((nt[j] & 0xFFFFu) && at0 < quota) && !(kNib && (nt[j] >> 16) && at1 < quota)) continue;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      uint32_t up, tie;
+      masks(d[k], up, tie);
+      // ties in rank order: inside a word the byte positions DESCEND with the rank
+      uint32_t m = at0 < quota ? tie & kEven : 0u;       // (behind the quota: nothing of this lane's any more)
+      while (m) {
+        const uint32_t bit = 31u - __clz(m);
+        m &= ~(1u << bit);
+        if (at0++ < quota) {
+          const uint32_t pos = bit / P::kBits;
+          admit((d[k] >> (pos * P::kBits)) & P::kMask, S::rank_of(wbase, (i * 4 + k) * P::kPerWord + pos));
+        }
+      }
+      if (kNib) {
+        m = at1 < quota ? tie & kOdd : 0u;
+        while (m) {
+          const uint32_t bit = 31u - __clz(m);
+          m &= ~(1u << bit);
+          if (at1++ < quota) {
+            const uint32_t pos = bit / P::kBits;
+            admit((d[k] >> (pos * P::kBits)) & P::kMask, S::rank_of(wbase, (i * 4 + k) * P::kPerWord + pos));
+          }
+        }
+      }
+      while (up) {
+        const uint32_t bit = __ffs(up) - 1;
+        up &= up - 1;
+        const uint32_t pos = bit / P::kBits;
+        admit((d[k] >> (pos * P::kBits)) & P::kMask, S::rank_of(wbase, (i * 4 + k) * P::kPerWord + pos));
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 12) sh->tally[tid] = 0;
+}
+
+// one step of a workgroup's windows: windows [w, w_end) of ONE pair (4-bit counters: both windows of the pair count
+// in one byte's nibbles, wbase is the even window's) or the one window w (byte counters)
+template <typename CT, int NT>
+__device__ __forceinline__ void one_step(const FindArgs& A, const uint32_t T, const uint32_t code, uint32_t* cnt32,
+                                         unsigned long long* pool, Control* ctl, OneShared* sh, const uint32_t w,
+                                         const uint32_t w_end) {
+  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t w_even = kNib ? (w & ~1u) : w;
+  uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+  if (lane < T) {
+    if (!kNib || w == w_even) { const uint2 se = A.slice_se[size_t(w_even) * kNumCodes + code]; a0 = se.x; b0 = se.y; }
+    if (kNib && w_even + 1 >= w && w_even + 1 < w_end) {
+      const uint2 se = A.slice_se[size_t(w_even + 1) * kNumCodes + code]; a1 = se.x; b1 = se.y;
+    }
+  }
+  if ((__ballot(b0 > a0) | __ballot(b1 > a1)) == 0) return;     // nothing of the needle in these windows (uniform)
+  ONE_MARK(A, 2);
+  const uint32_t wbase = w_even * kWindowRanks;
+  const uint32_t wlen = min((kNib ? 2u : 1u) * kWindowRanks, A.n_refs - wbase);
+  one_count<CT, NT>(A.ent, cnt32, a0, b0, a1, b1, wid, lane);
+  ONE_MARK(A, 3);
+  __syncthreads();
+  ONE_MARK(A, 4);
+  one_select<CT, NT>(A, reinterpret_cast<uint4*>(cnt32), T, A.keep, ctl, pool, sh, wbase, wlen);
+  ONE_MARK(A, 5);
+  // keep the best `keep` of what the pool holds now (at most twice that); the threshold follows
+  compact_pool<NT>(pool, ctl, kOnePool, A.keep);
+}
+
+struct OneArgs {
+  uint16_t codes[64];            // the needle's distinct trigram codes, ascending (tokeniser.c:59-119, by the host)
+  uint32_t T;                    // how many
+  uint32_t per;                  // windows per workgroup
+  unsigned long long* part_keys; // [grid * keep]: a workgroup's best keys ascending, padded with kKeyInf
+  uint32_t* flags;               // [grid] workgroup g's list is complete: the launch's sequence word
+  trigram_match_t* out_rows;     // host-coherent pinned memory: [keep]
+  uint32_t* out_count;           //   ... [0] = rows, [1] = the sequence word, written last
+  uint32_t seq;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const OneArgs O) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_counters[kWindowSize / 4];
+  __shared__ __attribute__((aligned(16))) unsigned long long s_pool[kOnePool];
+  __shared__ Control s_ctl;
+  __shared__ OneShared s_sh;
+  uint4* const cnt128 = reinterpret_cast<uint4*>(s_counters);
+  Control* const ctl = &s_ctl;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t g = blockIdx.x, G = gridDim.x;
+  ONE_MARK(A, 0);
+  // the needle's codes: lane t = trigram t (a load from the kernel-argument segment)
+  const uint32_t code = lane < O.T ? O.codes[lane] : 0u;
+  for (uint32_t i = tid; i < kWindowSize / 16; i += NT) cnt128[i] = make_uint4(0, 0, 0, 0);
+  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; ctl->pend_n[0] = 0; ctl->pend_n[1] = 0; }
+  if (tid < 12) s_sh.tally[tid] = 0;
+  __syncthreads();
+  ONE_MARK(A, 1);
+  const uint32_t T = O.T;
+  const uint32_t w0 = g * O.per, w1 = min(A.n_windows, w0 + O.per);
+  for (uint32_t w = w0; w < w1;) {
+    // 4-bit counters, both windows of a pair per step: any window for a needle of at most 15 trigrams, and for ANY
+    // needle the leading windows whose references have at most 15 (nib_windows: an even count) -- find_kernel's rule
+    if (T <= 15 || w < A.nib_windows) {
+      const uint32_t w_end = min(w1, (w | 1u) + 1u);
+      one_step<Nib, NT>(A, T, code, s_counters, s_pool, ctl, &s_sh, w, w_end);
+      w = w_end;
+    } else {
+      one_step<uint8_t, NT>(A, T, code, s_counters, s_pool, ctl, &s_sh, w, w + 1);
+      ++w;
+    }
+  }
+  ONE_MARK(A, 7);
+  const uint32_t nres = ctl->pool_n;                     // (sorted: every step ends with a compaction)
+  // ---- this workgroup's best keys (the list padded to `keep` slots, so that nobody needs its length), then its
+  // flag; the grid's LAST workgroup waits for everybody's flag and merges ------------------------------------------
+  // Keys and flags are written THROUGH to memory (agent-scope atomic stores: an XCD's L2 is not coherent with the
+  // others') and the flag goes out when the keys' stores have been acknowledged; the merging workgroup reads both the
+  // same way.  (First version: plain stores, __threadfence() -- a write-back of the XCD's whole L2, the sixteen
+  // workgroups of an XCD one after the other: 14 us -- and a ticket, atomicAdd on one word by 129 workgroups, performed
+  // at the memory side one after the other: another 13 us.  A workgroup that only spins on flags needs every other
+  // workgroup to RUN, not to be co-resident: the grid never exceeds the CUs, and nobody waits for the spinner.)
+  const uint32_t keep = A.keep;
+  if (g != G - 1) {
+    for (uint32_t i = tid; i < keep; i += NT)
+      __hip_atomic_store(&O.part_keys[size_t(g) * keep + i], i < nres ? s_pool[i] : kKeyInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ONE_MARK(A, 8);
+    if (tid == 0) __hip_atomic_store(&O.flags[g], O.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  ONE_MARK(A, 8);
+  {
+    uint32_t pending;
+    do {                                                 // lanes 0..G-2 of the first waves watch one flag each
+      const uint32_t f = tid < G - 1 ? __hip_atomic_load(&O.flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : O.seq;
+      pending = __syncthreads_or(f != O.seq);
+    } while (pending);
+  }
+  ONE_MARK(A, 9);
+  // The merge.  The answer lies among the keys that are not above H, the keep-th smallest of the lists' HEADS (keep
+  // heads are keep keys), and a key at place p of a list whose head has r smaller heads in front of it has r + p
+  // smaller keys in front of it: it passes only with r + p < keep.  At most keep (keep + 1) / 2 keys pass -- usually a
+  // few more than keep -- and compact_pool sorts those.  Every thread loads the lists' heads and its share of the
+  // first 8 192 slots AT ONCE (one global round trip; more slots -- a large grid times a large limit -- follow in
+  // further rounds).  (Through its first version the last workgroup merged like merge_parts_small_kernel, one wave
+  // advancing one list per round: every round a dependent load of a key another XCD had written, i.e. from memory --
+  // 2 us a row, 20 us at limit 10.)
+  constexpr uint32_t kPerThread = 8;
+  unsigned long long* const heads = s_pool;                            // [G]
+  uint32_t* const head_rank = reinterpret_cast<uint32_t*>(s_pool + kOneMaxGrid);   // [G] heads smaller than a list's
+  unsigned long long* const pool = reinterpret_cast<unsigned long long*>(s_counters);   // (the counters are done with)
+  constexpr uint32_t kMergeCap = kWindowSize / 8;                      // 8192 keys
+  static_assert(kMergeCap >= kOneMaxKeep * (kOneMaxKeep + 1) / 2 && kOnePool >= kOneMaxGrid + kOneMaxGrid / 2, "merge pool / heads");
+  const uint32_t own0 = g * keep;                                      // (this workgroup's own list -- the last -- comes from its pool)
+  unsigned long long mine[kPerThread];
+#pragma unroll
+  for (uint32_t j = 0; j < kPerThread; ++j) {
+    const uint32_t idx = tid + j * NT;
+    mine[j] = kKeyInf;
+    if (idx < own0) mine[j] = __hip_atomic_load(&O.part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned long long head = kKeyInf;
+  if (tid < g) head = __hip_atomic_load(&O.part_keys[size_t(tid) * keep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long own_key = kKeyInf;
+  if (tid < nres) own_key = s_pool[tid];                  // (before s_pool becomes the heads' array)
+  __syncthreads();
+  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; ctl->floor = kKeyInf; heads[g] = own_key; }
+  if (tid < g) heads[tid] = head;
+  __syncthreads();
+  ONE_MARK(A, 10);
+  if (tid < G) {                                         // H: the head with exactly keep - 1 heads below it (keys are distinct)
+    const unsigned long long h = heads[tid];
+    uint32_t below = 0;
+    const uint32_t G2 = G & ~1u;
+    for (uint32_t i = 0; i < G2; i += 2) {               // (two heads per read, the same address in every lane)
+      const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(heads + i);
+      below += uint32_t(two.x < h) + uint32_t(two.y < h);
+    }
+    if (G2 < G) below += heads[G2] < h ? 1u : 0u;
+    head_rank[tid] = h == kKeyInf ? keep : below;
+    if (h != kKeyInf && below == keep - 1) ctl->floor = h;
+  }
+  __syncthreads();
+  const unsigned long long H = ctl->floor;
+  auto pass = [&](const unsigned long long key, const uint32_t idx) {
+    if (key == kKeyInf || key > H) return;
+    const uint32_t list = idx / keep, p = idx - list * keep;
+    if (head_rank[list] + p >= keep) return;
+    const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
+    if (at < kMergeCap) pool[at] = key;                  // (never full: see the bound above)
+  };
+#pragma unroll
+  for (uint32_t j = 0; j < kPerThread; ++j) pass(mine[j], tid + j * NT);
+  for (uint32_t base = kPerThread * NT; base < own0; base += kPerThread * NT) {   // (beyond 8 192 slots: further rounds)
+#pragma unroll
+    for (uint32_t j = 0; j < kPerThread; ++j) {
+      const uint32_t idx = base + tid + j * NT;
+      mine[j] = idx < own0 ? __hip_atomic_load(&O.part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKeyInf;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPerThread; ++j) pass(mine[j], base + tid + j * NT);
+  }
+  pass(own_key, own0 + tid);
+  __syncthreads();
+  ONE_MARK(A, 11);
+  compact_pool<NT>(pool, ctl, kMergeCap, keep);
+  ONE_MARK(A, 12);
+  const uint32_t n_out = ctl->pool_n;
+  if (tid < n_out) {
+    const unsigned long long key = pool[tid];
+    const uint32_t rk = uint32_t(key);
+    trigram_match_t row;
+    row.reference = A.ref_of_rank[rk];
+    row.matches = T - uint32_t(key >> 32);
+    row.weight = A.weight_of_rank[rk];
+    O.out_rows[tid] = row;
+  }
+  if (tid == 0) O.out_count[0] = n_out;
+  ONE_MARK(A, 13);
+  if (tid < ((n_out + 63u) & ~63u) || tid < 64) __threadfence_system();   // rows and count are in host memory before the sequence word
+  __syncthreads();
+  ONE_MARK(A, 14);
+  if (tid == 0) __hip_atomic_store(&O.out_count[1], O.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // keys -> rows, in place: a needle's keys occupy the first 8 bytes of every 12-byte row slot's
 // worth of its result area (2 words per key, packed), so rows are written from the last to the
 // first -- row i lands on keys >= i only.  One lane per needle.
@@ -3539,6 +3971,26 @@ int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream) {
   if (a.n_work == 0) return 0;
   const uint32_t grid = std::min(a.n_work, n_cus * 4u);       // four workgroups per CU (LDS: 35 KiB each)
   hipLaunchKernelGGL(find_small_kernel, dim3(grid), dim3(kWsNT), 0, stream, a);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_find_one(const FindArgs& a, const uint16_t* codes, uint32_t T, uint32_t per, uint32_t grid,
+                    unsigned long long* part_keys, uint32_t* flags, trigram_match_t* out_rows,
+                    uint32_t* out_count, uint32_t seq, hipStream_t stream) {
+  OneArgs o;
+  for (uint32_t t = 0; t < 64; ++t) o.codes[t] = t < T ? codes[t] : uint16_t(0);
+  o.T = T; o.per = per; o.part_keys = part_keys; o.flags = flags;
+  o.out_rows = out_rows; o.out_count = out_count; o.seq = seq;
+  // (a workgroup has its CU to itself: with 69 KiB of LDS two of them fit a CU, and the one that is still counting
+  // then waits -- 27 us, measured -- while the other's waves sit in their serial sections; 24 KiB of dynamic LDS
+  // nobody touches keep the second workgroup off the CU: the grid never exceeds the CUs of the chip)
+  constexpr size_t kOneAloneLds = 24 * 1024;
+  static std::atomic<uint64_t> attr_done{0};
+  if (first_launch_on_this_device(attr_done))
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_one_kernel<kOneThreads>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(kOneAloneLds)));
+  hipLaunchKernelGGL((find_one_kernel<kOneThreads>), dim3(grid), dim3(kOneThreads), kOneAloneLds, stream, a, o);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }

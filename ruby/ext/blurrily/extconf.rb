@@ -12,8 +12,9 @@
 #   cd ruby/ext/blurrily && ruby extconf.rb && make      ->  blurrily/map_ext.so
 #
 # There is no Ruby in the image this repository is built in (SURVEY.md section 8(c)): the file is what a
-# maintainer runs, and is not exercised by tests/.  What IS checked there: that the reference's storage.h and
-# include/blurrily_storage.h agree declaration for declaration (tests/test_header_compat.py).
+# maintainer runs.  What IS checked by tests/: that the reference's storage.h and include/blurrily_storage.h agree
+# declaration for declaration (tests/test_header_compat.py), and that the two C sources below pass the compiler's
+# front end together under -Wall -Wextra -Werror (tests/test_ruby_glue_syntax.py).
 require 'mkmf'
 
 amd_root = ENV['BLURRILY_AMD_ROOT'] || File.expand_path('../../..', __dir__)
@@ -28,9 +29,10 @@ abort "#{gem_ext}/map_ext.c not found" unless File.exist?(File.join(gem_ext, 'ma
 abort "#{lib_dir}/libblurrily_hip.so not found: run `python -c 'import __graft_entry__ as g; g.build()'` in #{amd_root}" \
   unless File.exist?(File.join(lib_dir, 'libblurrily_hip.so'))
 
-# the glue is compiled from the gem's directory; the index sources beside it are NOT
-$VPATH    << gem_ext
-$srcs     = %w[map_ext.c map_ext_batch.c]
+# The gem's glue is compiled through map_ext_reference.c (this directory), which #includes the gem's own map_ext.c
+# from the gem's directory under one renamed symbol; the index sources beside it (storage.c, tokeniser.c,
+# search_tree.c) are NOT compiled: libblurrily_hip.so takes their place.
+$srcs     = %w[map_ext_reference.c map_ext_batch.c]
 $INCFLAGS << " -I#{gem_ext} -I#{File.join(amd_root, 'include')}"
 $LDFLAGS  << " -L#{lib_dir} -Wl,-rpath,#{lib_dir}"
 $libs     << ' -l:libblurrily_hip.so'
@@ -39,8 +41,5 @@ $libs     << ' -l:libblurrily_hip.so'
 platform = `uname`.strip.upcase
 $CFLAGS << " -DPLATFORM_#{platform} --std=c99 -Wall -Wextra -Os"
 $CFLAGS << ' -D_XOPEN_SOURCE=700 -D_GNU_SOURCE=1 -D_FILE_OFFSET_BITS=64' if platform == 'LINUX'
-# The gem's Init_map_ext defines Blurrily::RawMap; map_ext_batch.c defines the Init_map_ext Ruby calls, which runs
-# the gem's first and then adds the batched methods to the same class.
-$CFLAGS << ' -DInit_map_ext=Init_map_ext_reference'
 
 create_makefile('blurrily/map_ext')
