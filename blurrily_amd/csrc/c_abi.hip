@@ -148,6 +148,7 @@ struct trigram_map_t {
     DeviceBuffer   d_parts;             // [kOneMaxGrid * kOneMaxKeep keys | kOneMaxGrid flags]
     uint32_t       seq = 0;
     bool           enabled = true;      // option "one_launch"
+    uint32_t       min_per = 0;         // option "one_windows_per_wg": at least this many windows per workgroup (0: as few as the grid allows)
     uint64_t       taken = 0;           // finds served this way (option "one_taken", read-only)
   } one;
   // large host-buffer batches go in chunks through a three-stream pipeline (find_batch_chunked)
@@ -1188,6 +1189,7 @@ static int find_one(trigram_map m, const char* needle, uint16_t limit, trigram_m
   // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond
   uint32_t per = 1;
   if (ix.n_windows > kOneMaxGrid) { per = (ix.n_windows + kOneMaxGrid - 1) / kOneMaxGrid; per += per & 1u; }
+  per = std::max(per, O.min_per);                         // (a test's way to the several-steps-per-workgroup path on a small image)
   const uint32_t grid = (ix.n_windows + per - 1) / per;
   unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p);
   const uint32_t seq = ++O.seq ? O.seq : ++O.seq;         // (never 0: what the word holds before the first find)
@@ -1324,7 +1326,7 @@ constexpr OptionSlot kMapOptions[] = {
     {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64},
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
     {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
-    {"one_launch", 0, 1}, {"one_taken", 0, 0}};
+    {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1367,6 +1369,7 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 20: m->small_min_needles = uint32_t(std::min<long long>(value, 0xFFFFFFFFll)); break;
     case 21: m->one.enabled = value != 0; return 0;      // (the single find's own launch; nothing to measure again)
     case 22: return 0;                                   // (read-only)
+    case 23: m->one.min_per = uint32_t(value); return 0;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1409,6 +1412,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 20: *value = m->small_min_needles; return 0;
     case 21: *value = m->one.enabled; return 0;
     case 22: *value = (long long)m->one.taken; return 0;
+    case 23: *value = m->one.min_per; return 0;
     default: errno = EINVAL; return -1;
   }
 }
@@ -1439,42 +1443,6 @@ int blurrily_storage_find_path_flags(trigram_map m, uint32_t* out, size_t n) {
   BLURRILY_HIP_TRY(hipMemcpy(out, m->ws_flags.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return 0;
 }
-
-#ifdef BLURRILY_TRACE
-// debugging aid, trace build only (tools/touch_map.py): first-touch latency of a kernel's loads over the postings
-// array -- workgroup g loads `chunk` bytes at g * (bytes / n) of d_ent and notes the device's 100 MHz wall clock around
-// it: out[2 g] = start, out[2 g + 1] = duration, in 10 ns ticks
-namespace {
-__global__ __launch_bounds__(256) void touch_map_kernel(const unsigned char* base, size_t stride, uint32_t chunk16, unsigned long long* out) {
-  const unsigned long long t0 = wall_clock64();
-  const uint4* p = reinterpret_cast<const uint4*>(base + size_t(blockIdx.x) * stride);
-  uint32_t acc = 0;
-  for (uint32_t i = threadIdx.x; i < chunk16; i += 256) { const uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
-  __shared__ uint32_t s_acc;
-  if (threadIdx.x == 0) s_acc = 0;
-  __syncthreads();
-  atomicAdd(&s_acc, acc);
-  __syncthreads();
-  const unsigned long long t1 = wall_clock64();
-  if (threadIdx.x == 0) { out[2 * blockIdx.x] = t0 + (s_acc == 0x12345678u ? 1 : 0); out[2 * blockIdx.x + 1] = t1 - t0; }
-}
-}  // namespace
-int blurrily_debug_touch_map(trigram_map m, unsigned long long* out, uint32_t n, uint32_t chunk_bytes, int which) {
-  DeviceScope scope(m->dev.device);
-  unsigned long long* d_out = nullptr;
-  BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), size_t(n) * 16));
-  const unsigned char* base = which == 0 ? reinterpret_cast<const unsigned char*>(m->dev.d_ent)
-                                         : reinterpret_cast<const unsigned char*>(m->dev.d_slice_se);
-  const size_t bytes = which == 0 ? size_t(m->dev.n_slots) * 2 : size_t(m->dev.n_windows) * kNumCodes * 8;
-  const size_t stride = ((bytes - chunk_bytes) / n) & ~size_t(15);
-  hipLaunchKernelGGL(touch_map_kernel, dim3(n), dim3(256), 0, nullptr, base, stride, chunk_bytes / 16, d_out);
-  BLURRILY_HIP_TRY(hipDeviceSynchronize());
-  BLURRILY_HIP_TRY(hipMemcpy(out, d_out, size_t(n) * 16, hipMemcpyDeviceToHost));
-  (void)hipFree(d_out);
-  std::fprintf(stderr, "touch_map: base %p, %zu bytes, stride %zu\n", static_cast<const void*>(base), bytes, stride);
-  return 0;
-}
-#endif
 
 // debugging aid (tools/phase_profile.py): per-workgroup phase clocks of the last find launched while
 // blurrily_storage_set_stats was on

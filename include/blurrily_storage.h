@@ -89,7 +89,10 @@ int blurrily_storage_delete(trigram_map haystack, uint32_t reference);
 /* storage.h:110 / storage.c:477-580.  At most `limit` rows into the
  * caller-allocated `results`, ordered by matches descending, weight ascending,
  * reference ascending.  Returns the row count, or -1 (errno ENODEV) when no
- * GPU is usable. */
+ * GPU is usable.  ONE kernel launch and no copy for a needle of at most 64
+ * distinct trigrams at a limit of 1..120 on a map without mutations the device
+ * image has not absorbed yet (option "one_launch"); otherwise one element of
+ * blurrily_storage_find_batch. */
 int blurrily_storage_find(trigram_map haystack, const char* needle,
                           uint16_t limit, trigram_match results);
 
@@ -263,6 +266,9 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_cmin"         (3)     counted matches a left-out slice must leave
  *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing
  *                             it rebuilds the device image at the next find
+ *   "one_launch"      (1)     blurrily_storage_find as ONE launch without copies where it can be (see there); 0: always the
+ *                             batch's way.  "one_taken" (get): finds served that way so far.  "one_windows_per_wg" (0): at
+ *                             least this many windows per workgroup of that launch (0: as few as 256 workgroups allow)
  *   "host_chunk"      (131072) blurrily_storage_find_batch / _raw: a batch of at least twice as many needles goes
  *                             in chunks of this many through a three-stream pipeline (needles in, search, rows
  *                             out overlap); 0 = always one piece

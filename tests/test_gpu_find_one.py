@@ -1,0 +1,158 @@
+"""blurrily_storage_find as ONE launch (c_abi.hip: find_one, find_kernels.hip: find_one_kernel) -- the reference's
+only call shape (ext/blurrily/map_ext.c:131-162 -> storage.c:477-580) -- row for row against the live compiled
+reference (oracle/_ref, where it travelled) or the oracle, and against the batch's way on the same map:
+  * hypothesis-generated needles at limits 1 .. 120 on a haystack of five windows full of duplicate words (ties);
+  * thousands of IDENTICAL strings: a window whose counters tie by the thousand at the bound (storage.c:566's order:
+    the lowest references win);
+  * several windows per workgroup (option "one_windows_per_wg": the steps after the first arrive with a threshold);
+  * what must NOT take the launch: limits of 0 and above 120, needles of more than 64 distinct trigrams, maps with
+    pending puts or tombstones -- same rows, by the batch's way ("one_taken" tells which way a find went)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import workloads as W
+from blurrily_amd import RawMap
+from helpers import Oracle, Reference
+
+pytestmark = pytest.mark.gpu
+
+
+def _find(m, needle, limit):
+    rows = np.zeros((max(limit, 1), 3), dtype=np.uint32)
+    n = m._lib.blurrily_storage_find(m.handle, needle, limit, rows.ctypes.data)
+    assert n >= 0
+    return rows[:n].tolist()
+
+
+class _Checker:
+    """the live reference over a saved file when oracle/_ref is there, else the oracle"""
+
+    def __init__(self, m, hay, off):
+        self.ref, self.o, self.dir = None, None, None
+        if Reference.available():
+            self.dir = tempfile.TemporaryDirectory()
+            path = os.path.join(self.dir.name, "h.trigrams")
+            m.save(path)
+            self.ref = Reference(path)
+        else:
+            self.o = Oracle()
+            self.o.put_many(hay, off)
+
+    def find(self, needle, limit):
+        return self.ref.find(needle, limit) if self.ref else self.o.find(needle, limit)
+
+
+@pytest.fixture(scope="module")
+def geo():
+    n = 300_000                                              # five windows; 3 000 words: every string has twins
+    hay, off = W.geonames(n, 3000, 41)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    m.sync_device()
+    chk = _Checker(m, hay, off)
+    strings = W.unpack(hay, off)
+    return m, chk, strings
+
+
+def test_every_way_in_gives_the_reference_rows(geo):
+    m, chk, strings = geo
+    q, qo = W.queries(*_pack(strings[:4000]), 300, 5)
+    taken0 = m.get_option("one_taken")
+    n_one = 0
+    for limit in (1, 2, 10, 64, 100, 120):
+        for nd in W.unpack(q, qo)[:120] + [strings[7], strings[70000], strings[299999], b"", b"a", b"zzzzqqqq"]:
+            want = chk.find(nd, limit)
+            assert _find(m, nd, limit) == want, (nd, limit)
+            n_one += 1
+    assert m.get_option("one_taken") - taken0 >= n_one - 6 * 3      # (needles without a posting return before any launch)
+    # the batch's way gives the same rows (one_launch 0)
+    m.set_option("one_launch", 0)
+    t = m.get_option("one_taken")
+    for nd in W.unpack(q, qo)[:40]:
+        assert _find(m, nd, 10) == chk.find(nd, 10)
+    assert m.get_option("one_taken") == t
+    m.set_option("one_launch", 1)
+
+
+def _pack(strings):
+    packed = np.frombuffer(b"".join(strings), dtype=np.uint8)
+    off = np.zeros(len(strings) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    return packed, off
+
+
+@settings(max_examples=int(os.environ.get("BLURRILY_FUZZ_ONE", "150")), deadline=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(needle=st.text(alphabet="abcdefghijklmnopqrstuvwxyz ", min_size=0, max_size=48),
+       pick=st.integers(0, 299_999), edits=st.integers(0, 3), limit=st.sampled_from([1, 3, 10, 37, 64, 120]),
+       use_pick=st.booleans())
+def test_hypothesis_single_finds_against_the_reference(geo, needle, pick, edits, limit, use_pick):
+    m, chk, strings = geo
+    nd = needle.encode()
+    if use_pick:                                             # a haystack string, a few characters dropped: close matches and ties
+        nd = bytearray(strings[pick])
+        for k in range(min(edits, max(len(nd) - 1, 0))):
+            del nd[(pick * 7 + k * 13) % len(nd)]
+        nd = bytes(nd)
+    assert _find(m, nd, limit) == chk.find(nd, limit), (nd, limit)
+
+
+def test_thousands_of_identical_strings_tie_at_the_bound():
+    """windows whose counters tie by the thousand: the lowest references win (storage.c:566 over ref-sorted
+    input, spec/integration_spec.rb:37-42), whichever window they sit in"""
+    rng = np.random.default_rng(3)
+    base = [b"san jose", b"san juan", b"santa fe", b"saint john", b"sao jose dos campos"]
+    hay_strings = [base[i % 5] if (i % 3) else bytes(rng.integers(97, 123, size=int(rng.integers(3, 14))).astype(np.uint8))
+                   for i in range(200_000)]
+    packed, off = _pack(hay_strings)
+    refs = rng.permutation(np.arange(1, 200_001)).astype(np.uint32)          # references in no order: ranks decide
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(packed, off, refs)
+    o.put_many(packed, off, refs)
+    taken0 = m.get_option("one_taken")
+    for nd in (b"san jose", b"san juan", b"san", b"saint", b"jose", b"sao jose", b"s"):
+        for limit in (1, 10, 64, 120):
+            assert _find(m, nd, limit) == o.find(nd, limit), (nd, limit)
+    assert m.get_option("one_taken") - taken0 == 7 * 4
+    for per in (2, 3, 64):                                   # several windows per workgroup: steps that arrive with a threshold
+        m.set_option("one_windows_per_wg", per)
+        for nd in (b"san jose", b"santa", b"saint john"):
+            for limit in (1, 10, 120):
+                assert _find(m, nd, limit) == o.find(nd, limit), (nd, limit, per)
+    m.set_option("one_windows_per_wg", 0)
+
+
+def test_what_goes_the_batchs_way_instead(geo):
+    m0, chk, strings = geo
+    hay_strings = strings[:30_000]
+    packed, off = _pack(hay_strings)
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(packed, off, np.arange(1, 30_001, dtype=np.uint32))
+    o.put_many(packed, off)
+    nd = hay_strings[11]
+
+    def goes_one(needle, limit):
+        t = m.get_option("one_taken")
+        assert _find(m, needle, limit) == o.find(needle, limit), (needle, limit)
+        return m.get_option("one_taken") - t
+
+    assert goes_one(nd, 10) == 1
+    assert goes_one(nd, 120) == 1
+    assert goes_one(nd, 121) == 0 and goes_one(nd, 1024) == 0               # limits above the launch's
+    assert _find(m, nd, 0) == []                                            # limit 0: no rows (the C entry point takes it as it is)
+    long_needle = b" ".join(hay_strings[k] for k in range(20, 40))[:250]    # more than 64 distinct trigrams
+    assert len(set(Oracle.tokenise(long_needle))) > 64 and goes_one(long_needle, 10) == 0
+    # a pending put: base + delta images, merged -- the batch's way until the log folds into a rebuilt base
+    assert m.put(b"zanzibar city", 40_001, 0) > 0 and o.put(b"zanzibar city", 40_001, 0) > 0
+    assert goes_one(b"zanzibar city", 10) == 0 and goes_one(nd, 10) == 0
+    # a tombstone
+    assert m.delete(12) == o.delete(12)
+    assert goes_one(nd, 10) == 0
+    # timing mode describes the batch's launches: not taken either
+    m.set_timing(True)
+    assert goes_one(nd, 10) == 0
+    m.set_timing(False)

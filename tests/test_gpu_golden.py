@@ -32,10 +32,13 @@ def test_hip_matches_reference_fixture(name):
     assert m.stats() == g["stats"]
     needles = [bytes.fromhex(h) for h in g["needles_hex"]]
     assert _batch(m, needles, g["limit"]) == g["expected"]
-    for nd, want in list(zip(needles, g["expected"]))[:10]:           # the single-needle entry point too
+    taken = m.get_option("one_taken")
+    for nd, want in zip(needles, g["expected"]):                     # EVERY needle through the single-needle entry point too
         rows = (np.zeros((g["limit"], 3), dtype=np.uint32))
         n = m._lib.blurrily_storage_find(m.handle, nd, g["limit"], rows.ctypes.data)
         assert rows[:n].tolist() == want
+    if g["limit"] <= 120:                                            # ... which went as ONE launch (c_abi.hip: find_one)
+        assert m.get_option("one_taken") - taken >= sum(1 for w in g["expected"] if w)
 
 
 @pytest.mark.skipif(not Reference.available(), reason="oracle/_ref did not travel with the snapshot")
