@@ -31,6 +31,8 @@ class DeviceInfo(C.Structure):
         ("n_pending", C.c_uint32), ("n_tombstones", C.c_uint32), ("base_builds", C.c_uint64),
         ("mean_hit_slice", C.c_double), ("n_bitmaps", C.c_uint32), ("reserved_", C.c_uint32),
         ("dense_share", C.c_double), ("ws_gain", C.c_double),
+        ("n_replicas", C.c_uint32), ("distinct_devices", C.c_uint32), ("peer_access_mask", C.c_uint32),
+        ("same_device_mask", C.c_uint32), ("pci_bus_id", C.c_char * 16),
     ]
 
 

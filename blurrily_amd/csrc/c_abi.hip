@@ -81,6 +81,8 @@ struct trigram_map_t;
 // buffers, events and measured choices its finds need, a stream, and staging for its shard of a batch.
 struct Replica {
   int            device = -1;
+  bool           same_device = false;   // it sits on the primary's own device (more replicas than devices)
+  bool           peer_access = false;   // its device and the primary's reach each other's memory directly (both ways, enabled)
   trigram_map_t* side = nullptr;        // dev / delta / d_code_total_now are the clones; host == nullptr; mirror_of = the primary
   uint64_t       base_builds = 0, delta_image_version = 0, log_version = 0;   // the primary's, as of the clones
   hipStream_t    stream = nullptr;
@@ -660,6 +662,29 @@ int ensure_replicas(trigram_map m) {
     r.side = new (std::nothrow) trigram_map_t();
     if (!r.side) { errno = ENOMEM; return -1; }
     r.side->mirror_of = m;
+    // The shard's needles reach the replica, and its rows the caller's buffers, by hipMemcpyPeerAsync.  With peer
+    // access enabled BOTH ways those copies are the devices' own, point to point (xGMI on an MI355X node); without it
+    // the runtime stages them through host memory -- same rows, and said so once on stderr, since that is not the
+    // gather SURVEY.md section 8(e) describes.
+    r.same_device = r.device == m->dev.device;
+    if (!r.same_device) {
+      int to = 0, from = 0;
+      const bool can = hipDeviceCanAccessPeer(&to, m->dev.device, r.device) == hipSuccess && to &&
+                       hipDeviceCanAccessPeer(&from, r.device, m->dev.device) == hipSuccess && from;
+      bool on_ = can;
+      if (can) {
+        for (int pass = 0; pass < 2 && on_; ++pass) {
+          DeviceScope here(pass ? r.device : m->dev.device);
+          const hipError_t e = hipDeviceEnablePeerAccess(pass ? m->dev.device : r.device, 0);
+          if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          else if (e != hipSuccess) on_ = false;
+        }
+      }
+      r.peer_access = on_;
+      if (!on_)
+        std::fprintf(stderr, "blurrily_hip: no peer access between device %d and device %d (%s): the rows of that replica "
+                             "travel through host memory\n", m->dev.device, r.device, can ? "enabling it failed" : "not offered");
+    }
     DeviceScope on(r.device);
     if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -722,8 +747,8 @@ int ensure_replicas(trigram_map m) {
 // stream and sends its block of rows (and counts, nb_entries) straight into the caller's buffers by peer copies --
 // the gather of SURVEY.md section 8(e), point to point over xGMI.  Everything is enqueued: `stream` waits for the
 // replicas' events, the host for nothing (timing mode apart).
-int run_find_multi(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
-                   uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, hipStream_t stream) {
+int run_find_multi_enqueue(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
+                           uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, hipStream_t stream) {
   if (apply_tombstones(m, stream) < 0) return -1;             // (the bits are set before the replicas copy the bitmap)
   if (ensure_replicas(m) < 0) return -1;
   const size_t R = m->replicas.size() + 1;
@@ -791,6 +816,26 @@ int run_find_multi(trigram_map m, const char* d_packed, size_t packed_bytes, con
     m->last_tok_ms = 0.0;
   }
   return 0;
+}
+
+// ... and what a failure half-way must not leave behind: the timing mode switched off, replicas still searching and
+// copying into the caller's buffers
+int run_find_multi(trigram_map m, const char* d_packed, size_t packed_bytes, const uint64_t* d_offsets, size_t n,
+                   uint16_t limit, trigram_match d_results, uint32_t* d_counts, uint32_t* d_nb, hipStream_t stream) {
+  const bool timing = m->timing;
+  const int rc = run_find_multi_enqueue(m, d_packed, packed_bytes, d_offsets, n, limit, d_results, d_counts, d_nb, stream);
+  if (rc < 0) {
+    const int e = errno;
+    m->timing = timing;
+    for (Replica& r : m->replicas) {
+      if (!r.stream) continue;
+      DeviceScope on(r.device);
+      (void)hipStreamSynchronize(r.stream);
+    }
+    (void)hipStreamSynchronize(stream);
+    errno = e;
+  }
+  return rc;
 }
 
 // a batch goes over the replicas when "devices" asks for them and it is big enough to be worth a peer copy per
@@ -1277,6 +1322,25 @@ int blurrily_storage_device_info(trigram_map m, blurrily_device_info_t* info) {
   info->reserved_ = 0;
   info->dense_share = m->dev.dense_share;
   info->ws_gain = m->dev.ws_gain;
+  // what the replicas sit on: physical devices by PCI bus id
+  info->n_replicas = uint32_t(m->replicas.size());
+  info->peer_access_mask = 0; info->same_device_mask = 0;
+  std::memset(info->pci_bus_id, 0, sizeof info->pci_bus_id);
+  std::vector<std::string> seen;
+  auto bus_of = [](int dev) { char b[32] = {0}; if (dev < 0 || hipDeviceGetPCIBusId(b, sizeof b, dev) != hipSuccess) b[0] = 0; return std::string(b); };
+  if (m->dev.device >= 0) {
+    const std::string mine = bus_of(m->dev.device);
+    std::snprintf(info->pci_bus_id, sizeof info->pci_bus_id, "%s", mine.c_str());
+    seen.push_back(mine.empty() ? "dev" + std::to_string(m->dev.device) : mine);
+  }
+  for (size_t k = 0; k < m->replicas.size(); ++k) {
+    const Replica& r = m->replicas[k];
+    if (k < 32) { info->peer_access_mask |= uint32_t(r.peer_access) << k; info->same_device_mask |= uint32_t(r.same_device) << k; }
+    std::string b = bus_of(r.device);
+    if (b.empty()) b = "dev" + std::to_string(r.device);
+    if (std::find(seen.begin(), seen.end(), b) == seen.end()) seen.push_back(b);
+  }
+  info->distinct_devices = uint32_t(seen.size());
   return 0;
 }
 
@@ -1362,7 +1426,10 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 10: m->nm_cmin = uint32_t(value); break;
     case 11: m->nm_dense = uint32_t(value); break;
     case 12: m->last_sweep = 0; return 0;                // (value 0 only; nothing to measure again)
-    case 13: m->n_devices = uint32_t(value); return 0;   // (replicas are made, or dropped, by the next large batch)
+    case 13:                                             // (replicas are made by the next large batch; dropped at once)
+      m->n_devices = uint32_t(value);
+      while (m->replicas.size() + 1 > m->n_devices) { free_replica(m->replicas.back()); m->replicas.pop_back(); }
+      return 0;
     case 14: m->nm_min_windows = uint32_t(value); break;
     case 15: case 16: case 17: case 18: return 0;        // (read-only: what the last measurement saw)
     case 19: m->small_sweep = value != 0; break;

@@ -199,6 +199,15 @@ typedef struct blurrily_device_info_t {
   double   dense_share;         /* share of those postings in slices dense enough to have a bitmap  */
   double   ws_gain;             /* the four biggest buckets' part of mean_hit_slice x postings per
                                    reference: postings a needle can expect to leave out per window */
+  /* option "devices" (round 5): what the replicas of the image actually sit on */
+  uint32_t n_replicas;          /* copies of the image beside the primary's (0: "devices" 1, or none made yet)   */
+  uint32_t distinct_devices;    /* PHYSICAL devices holding a copy, the primary's included (by PCI bus id): more
+                                   replicas than devices share devices, and a batch is then no faster for them   */
+  uint32_t peer_access_mask;    /* bit k: replica k's device and the primary's reach each other's memory directly
+                                   (hipDeviceCanAccessPeer both ways, enabled): rows travel point to point over
+                                   xGMI; bit clear: the peer copies of that replica are staged by the runtime     */
+  uint32_t same_device_mask;    /* bit k: replica k sits on the primary's own device (no link involved)          */
+  char     pci_bus_id[16];      /* the primary's device, "0000:c1:00.0"                                          */
 } blurrily_device_info_t;
 int blurrily_storage_device_info(trigram_map haystack, blurrily_device_info_t* info);
 /* The same for a caller compiled against another version of this header: at most

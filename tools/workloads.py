@@ -96,15 +96,71 @@ BENCH_WORKLOADS = {
                           label="four times configs[2]'s haystack (33.7M strings), 100k batched needles"),
     # ... and needles WITHOUT a close match: configs[2]'s haystack, needles cut from a haystack of another seed's
     # vocabulary -- what the reference's own bench does with its fixed city names on any dataset (bin/bench:24-25,160-162)
+    # configs[0-1] name /usr/share/dict/words: benched where the box has the file (bench.py records its SHA-256, or
+    # that it looked and found none); `words` above is its seeded stand-in, which the digests of tests/golden hold
+    "dict_words": dict(kind="dict", n=0, hay_seed=0, queries=100_000, limit=10,
+                       label="configs[1] on the box's own /usr/share/dict/words, 100k batched needles"),
     "geonames_miss": dict(kind="geonames", n=8423769, vocab=500000, hay_seed=3, queries=100_000, limit=10,
                           needles_from=dict(n=200_000, vocab=500000, seed=1003),
                           label="configs[2]'s haystack, 100k needles from a foreign vocabulary (no close match)"),
 }
 
 
+DICT_WORDS_PATH = "/usr/share/dict/words"       # BASELINE.json configs[0-1] name it; SURVEY.md 8(d): "if the box has it"
+
+
+def dict_words(path=DICT_WORDS_PATH):
+    """The box's own word list as a haystack, or None where there is none: one string per line, as Blurrily::Map#put
+    would index it (lib/blurrily/map.rb:40-47 for ASCII: downcase, everything but a-z a space, squeezed, stripped;
+    lines with a byte >= 0x80 and lines that come out empty are left out).  Returns (packed, offsets, sha256 of the file)."""
+    import hashlib
+    import re
+    if not os.path.isfile(path):
+        return None
+    raw = open(path, "rb").read()
+    out = []
+    for line in raw.split(b"\n"):
+        if not line or max(line) >= 0x80:
+            continue
+        s = b" ".join(re.sub(rb"[^a-z]", b" ", line.lower()).split())
+        if s:
+            out.append(s)
+    packed = np.frombuffer(b"".join(out), dtype=np.uint8).copy()
+    off = np.zeros(len(out) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in out])
+    return packed, off, hashlib.sha256(raw).hexdigest()
+
+
+# the eight needles of the reference's own benchmark (bin/bench:24-25), as Map#find hands them to the C call
+PUBLISHED_NEEDLES = [b"london", b"paris", b"rome", b"luxembourg", b"lonndon", b"pari", b"roma", b"luxenbour"]
+# record counts of its six datasets (doc/bench.numbers; BASELINE.md section 1): cities .. world
+PUBLISHED_RECORDS = [131_002, 347_014, 474_695, 828_647, 2_158_158, 8_423_769]
+# what the synthetic haystacks of that curve end with, so that the needles have something to find (the real datasets
+# hold these places; a haystack of pseudo-words does not)
+PUBLISHED_PLACES = [b"london", b"paris", b"rome", b"luxembourg", b"london city airport", b"paris texas", b"roma termini",
+                    b"luxembourg ville"]
+
+
+def published_haystack(records):
+    """A Geonames-kind haystack of `records` strings (same generator and vocabulary rule as configs[2]) whose last eight
+    strings are PUBLISHED_PLACES."""
+    hay, off = geonames(records, max(1000, min(500000, records // 16)), 3)
+    strings_end = int(off[records - len(PUBLISHED_PLACES)])
+    tail = b"".join(PUBLISHED_PLACES)
+    packed = np.concatenate([hay[:strings_end], np.frombuffer(tail, dtype=np.uint8)])
+    off = off.copy()
+    off[records - len(PUBLISHED_PLACES) + 1:] = strings_end + np.cumsum([len(s) for s in PUBLISHED_PLACES]).astype(np.uint64)
+    return packed, off
+
+
 def bench_haystack(name, scale=1.0):
     """(packed, offsets) of the haystack bench.py indexes for `name` (refs are 1..n, weight 0)."""
     spec = BENCH_WORKLOADS[name]
+    if spec["kind"] == "dict":
+        got = dict_words()
+        if got is None:
+            raise FileNotFoundError(DICT_WORDS_PATH)
+        return got[0], got[1]
     n = max(1000, int(spec["n"] * scale))
     if spec["kind"] == "geonames":
         return geonames(n, max(1000, int(spec["vocab"] * min(1.0, scale * 4))), spec["hay_seed"])
