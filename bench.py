@@ -372,6 +372,13 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             base += int(o_[-1])
         qo = np.concatenate(offs)
         m.set_option("devices", devices)
+    elif getattr(args, "scaling", "weak") == "strong" and world > 1:
+        # configs[3]'s literal batch: 8 x the workload's needles in all, rank r searching shard r of them (the shards'
+        # needles are generated per rank, seeded by the rank: nobody holds the 8 M)
+        from blurrily_amd.sharding import shard_bounds
+        total = 8 * max(100, int(spec["queries"] * args.scale))
+        lo, hi = shard_bounds(total, world, rank)
+        qp, qo = W.queries(hay, hay_off, hi - lo, 4000 + rank)
     else:
         qp, qo = W.bench_needles(hay, hay_off, name, args.scale, rank, world)
     n_q = len(qo) - 1
@@ -521,11 +528,22 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     totals = torch.tensor([float(sum_nb), k_ms, float(np.mean(gather_ms)) if gather_ms else 0.0],
                           dtype=torch.float64, device=coll_dev)
     per_rank = None
-    device_ids, device_names = [local_rank], [torch.cuda.get_device_name(local_rank)]
+
+    def physical_id(i):
+        # what tells two ranks on ONE GPU from two GPUs: the device's UUID, else its PCI address
+        pr = torch.cuda.get_device_properties(i)
+        u = getattr(pr, "uuid", None)
+        if u is not None:
+            return str(u)
+        return "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", i), getattr(pr, "pci_device_id", 0))
+    device_ids, device_names, device_phys = [local_rank], [torch.cuda.get_device_name(local_rank)], [physical_id(local_rank)]
+    n_q_all = [n_q]
     if world > 1:
         ids = [None] * world
-        dist.all_gather_object(ids, (torch.cuda.current_device(), torch.cuda.get_device_name(torch.cuda.current_device())))
-        device_ids, device_names = [i for i, _ in ids], [nm for _, nm in ids]
+        cur = torch.cuda.current_device()
+        dist.all_gather_object(ids, (cur, torch.cuda.get_device_name(cur), physical_id(cur), n_q))
+        device_ids, device_names = [i for i, _, _, _ in ids], [nm for _, nm, _, _ in ids]
+        device_phys, n_q_all = [ph for _, _, ph, _ in ids], [q_ for _, _, _, q_ in ids]
         allr = [torch.zeros_like(totals) for _ in range(world)]
         dist.all_gather(allr, totals)
         per_rank = [[float(x) for x in t.tolist()] for t in allr]
@@ -564,13 +582,18 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                                    np.where((np.arange(limit)[None, :] < gpu_counts[:, None])[:, :, None], gpu_rows, 0))):
                 raise RuntimeError("host-buffer batch (chunked pipeline) and device-resident batch disagree")
         info = m.device_info()
+        # PHYSICAL devices that served: ranks (or in-process replicas) sharing a GPU are not GPUs.  n_gpus is that count --
+        # never the number of ranks asked for -- and `replicas` says how many shards there were
+        distinct = int(info["distinct_devices"]) if devices > 1 else len(set(device_phys))
+        strong = getattr(args, "scaling", "weak") == "strong" and world > 1
         out = {
             "metric": "find() queries/sec (batched), Geonames-scale haystack",
-            "value": world * n_q * steps / elapsed,
+            "value": sum(n_q_all) * steps / elapsed,
             "unit": "queries/s",
-            "n_gpus": world * devices, "steps": steps, "warmup": warmup,
+            "n_gpus": distinct, "replicas": world * devices, "distinct_devices": distinct,
+            "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": spec["label"], "haystack_strings": int(len(hay_off) - 1),
                        "haystack_entries": int(entries_resident), "needles_per_gpu": n_q // devices, "limit": limit,
@@ -648,6 +671,13 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "resident_index_bytes": int(info["device_bytes"])},
         }
         out["unpinned"] = UNPINNED
+        if devices > 1:
+            out["in_process"] = {"replicas": devices, "distinct_devices": distinct, "n_replicas_made": int(info["n_replicas"]),
+                                 "peer_access_mask": int(info["peer_access_mask"]), "same_device_mask": int(info["same_device_mask"]),
+                                 "primary_pci_bus_id": info["pci_bus_id"].decode() if isinstance(info["pci_bus_id"], bytes) else str(info["pci_bus_id"])}
+        if distinct < world * devices:
+            log(f"NOTE: {world * devices} shards were served by {distinct} physical device(s): the line says n_gpus {distinct}; "
+                f"this is a plumbing run, not a scaling point")
         if world > 1:
             # what the collective ran on: enough to tell an RCCL run over N devices from anything else
             out["collective"] = {
@@ -655,6 +685,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version())
                                  if dist.get_backend() == "nccl" else None),
                 "device_ids": device_ids, "device_names": sorted(set(device_names)),
+                "physical_devices": sorted(set(device_phys)), "distinct_devices": len(set(device_phys)),
                 "op": "gather to rank 0, one per step, async (issued behind the search, waited for before the block is reused)"}
             out["per_rank"] = {"kernel_ms": [p[1] for p in per_rank], "gather_ms": [p[2] for p in per_rank]}
             out["gather_ms"] = float(np.mean(gather_ms))
@@ -696,6 +727,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
     ap.add_argument("--latency-probes", type=int, default=200)
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N > 1: weak = every rank its own batch of the workload's size (1 M needles per GPU at configs[2]); "
+                         "strong = configs[3]'s literal batch, 8 M needles in all at Geonames scale (8 x the workload's), cut "
+                         "into N contiguous shards (blurrily_amd/sharding.py: shard_bounds)")
     ap.add_argument("--in-process", action="store_true",
                     help="--gpus N in ONE process: the image replicated on N devices behind the C ABI (option \"devices\"), "
                          "the N ranks' needles in one call; no torch.distributed")

@@ -182,7 +182,11 @@ def test_bench_two_ranks_plumbing(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    # n_gpus counts PHYSICAL devices (two ranks on this box's one GPU are one GPU); `replicas` the shards
+    import torch
+    phys = min(2, torch.cuda.device_count())
+    assert d["n_gpus"] == d["distinct_devices"] == phys and d["replicas"] == 2 and d["collective"]["distinct_devices"] == phys
+    assert d["steps"] == 2 and d["scaling"] == "weak"
     assert d["config"]["needles_per_gpu"] == 50000 and d["config"]["index_replicated"] is True
     assert abs(d["value"] - 2 * 50000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6      # whole-job needles/s
     assert len(d["per_rank"]["kernel_ms"]) == 2 and len(d["per_rank"]["gather_ms"]) == 2
@@ -192,6 +196,31 @@ def test_bench_two_ranks_plumbing(tmp_path):
     assert "cpu_baseline" not in d and "extra_configs" not in d
     # which backend and devices the collective ran on (RCCL on the driver's multi-GPU runs; gloo here)
     assert d["collective"]["backend"] == "gloo" and d["collective"]["world"] == 2 and len(d["collective"]["device_ids"]) == 2
+
+
+def test_bench_two_ranks_strong_scaling_plumbing():
+    """`--scaling strong`: configs[3]'s literal batch -- 8 x the workload's needles IN ALL -- cut into contiguous shards
+    (shard_bounds), here over two ranks sharing the box's GPU, gloo; the line says strong, the value counts every
+    rank's needles once."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BLURRILY_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--scale", "0.02", "--scaling", "strong"]
+    res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    total = 8 * 20000
+    assert d["scaling"] == "strong" and d["replicas"] == 2 and d["config"]["needles_per_gpu"] == total // 2
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
 def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
@@ -252,10 +281,10 @@ def test_bench_fails_loudly_when_a_leg_fails():
     assert res.returncode == 1, (res.returncode, res.stderr[-1500:])
     assert d is not None and "injected failure" in d["extra_configs"]["words"]["cpu_baseline"]["error"]
     # the legs that did not fail are whole, parity floor included (32 needles whatever the budget)
-    assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 32
+    assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 64
     for name in ("skewed", "geonames_x4", "geonames_miss"):
         x = d["extra_configs"][name]
-        assert "error" not in x and x["parity_checked"] >= 32 and x["cpu_baseline"]["parity_mismatches"] == 0, (name, x)
+        assert "error" not in x and x["parity_checked"] >= 64 and x["cpu_baseline"]["parity_mismatches"] == 0, (name, x)
         assert x["roofline"]["counted_launch_rows_equal_timed"] is True and x["roofline"]["sweep"] == x["roofline"]["counted_sweep"]
     res, d = _run_bench(["--steps", "2", "--warmup", "1", "--scale", "0.02", "--cpu-budget", "1", "--latency-probes", "0",
                          "--no-extra", "--inject-failure", "geonames"])
@@ -269,6 +298,11 @@ def test_bench_in_process_over_two_logical_devices():
     res, d = _run_bench(["--gpus", "2", "--in-process", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--cpu-budget", "1",
                          "--latency-probes", "0"])
     assert res.returncode == 0, res.stderr[-2000:]
-    assert d["n_gpus"] == 2 and d["config"]["needles_per_gpu"] == 50000 and "in-process" in d["config"]["parallelism"]
+    # with one GPU on the box both replicas share it: the line does not call that two GPUs
+    import torch
+    phys = min(2, torch.cuda.device_count())
+    assert d["n_gpus"] == d["distinct_devices"] == d["in_process"]["distinct_devices"] == phys and d["replicas"] == 2
+    assert d["in_process"]["n_replicas_made"] == 1 and d["in_process"]["same_device_mask"] == (1 if phys == 1 else 0)
+    assert d["config"]["needles_per_gpu"] == 50000 and "in-process" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 50000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
-    assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 32 and "extra_configs" not in d
+    assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 64 and "extra_configs" not in d

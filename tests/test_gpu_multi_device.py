@@ -119,3 +119,25 @@ def test_replicas_follow_puts_and_deletes():
     check()
     assert m.device_info()["base_builds"] == builds + 1
     m.close()
+
+
+def test_device_info_says_what_the_replicas_sit_on(pair):
+    """`n_gpus: 2` with both replicas on one GPU.  The library reports the PHYSICAL devices holding a copy
+    (PCI bus ids), which replicas share the primary's device and which reach it by peer access; "devices" back to 1
+    drops the replicas at once."""
+    import torch
+    m, o, hay, off = pair
+    visible = torch.cuda.device_count()
+    q, qo = W.queries(hay, off, 8192, 5)
+    m.set_option("devices", 4)
+    m.find_batch_packed(q, qo, 10)
+    info = m.device_info()
+    assert info["n_replicas"] == 3 and info["distinct_devices"] == min(4, visible)
+    assert info["pci_bus_id"] and len(info["pci_bus_id"]) >= 7
+    # replica k lives on device (primary + 1 + k) mod visible: with one GPU all three share the primary's
+    want_same = sum(1 << k for k in range(3) if (info["device_ordinal"] + 1 + k) % visible == info["device_ordinal"])
+    assert info["same_device_mask"] == want_same
+    assert info["peer_access_mask"] & info["same_device_mask"] == 0
+    m.set_option("devices", 1)
+    info = m.device_info()
+    assert info["n_replicas"] == 0 and info["distinct_devices"] == 1

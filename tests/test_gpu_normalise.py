@@ -76,6 +76,15 @@ def test_spec_vectors_and_edges():
         assert g == want, (nd, g, want)
         assert gi == want, (nd, gi, want)
     assert not flags.any()
+    # the reference-held vectors (every spec string that reaches normalize_string, tests/golden/spec_vectors.json): the
+    # ASCII ones through the device normaliser, held to the form the spec's own assertion implies
+    from helpers import load_golden
+    vecs = [v for v in load_golden("spec_vectors.json")["normalize"] if all(ord(c) < 0x80 for c in v["raw"])]
+    assert len(vecs) >= 12
+    got, got_inplace, flags = _device_normalise([v["raw"].encode() for v in vecs])
+    for v, g, gi in zip(vecs, got, got_inplace):
+        assert g == gi == v["normalized"].encode(), (v, g, gi)
+    assert not flags.any()
 
 
 def test_random_ascii_needles_match_the_oracle_normaliser():

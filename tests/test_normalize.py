@@ -7,7 +7,22 @@ from helpers import load_golden
 
 @pytest.mark.parametrize("vec", load_golden("spec_vectors.json")["normalize"], ids=lambda v: v["raw"])
 def test_spec_vectors(vec):
-    assert normalize_string(vec["raw"]) == vec["normalized"]
+    """every string of the reference's specs that reaches normalize_string (map_spec.rb, command_processor_spec.rb,
+    integration_spec.rb), with the normalised form the spec's own assertion implies: where the spec states a trigram
+    count or a weight (= strlen, storage.c:409), the form must have exactly that many"""
+    from helpers import Oracle
+    got = normalize_string(vec["raw"])
+    assert got == vec["normalized"]
+    if "trigrams" in vec:
+        assert len(Oracle.tokenise(got.encode())) == vec["trigrams"]
+    if "weight" in vec:
+        assert len(got.encode()) == vec["weight"]
+    if all(ord(c) < 0x80 for c in vec["raw"]):                  # the independent checker agrees (ASCII input)
+        assert Oracle.normalize_ascii(vec["raw"].encode()) == vec["normalized"].encode()
+
+
+def test_at_least_a_dozen_reference_held_normaliser_vectors():
+    assert len(load_golden("spec_vectors.json")["normalize"]) >= 12
 
 
 def test_frozen_non_ascii_vectors():

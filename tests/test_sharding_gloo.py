@@ -23,6 +23,19 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_configs3_batch_of_eight_million_over_eight_ranks():
+    """BASELINE.json configs[3]: an 8 M-needle batch sharded over the 8 GPUs of a node (bench.py --scaling strong):
+    contiguous shards of one million each, and what ONE gather then moves (~124 MB per peer)."""
+    spans = [shard_bounds(8_000_000, 8, r) for r in range(8)]
+    assert spans == [(r * 1_000_000, (r + 1) * 1_000_000) for r in range(8)]
+    assert block_bytes(1_000_000, 10) == 124_000_000
+    # a batch that does not divide: the first ranks take one more, nothing is lost or doubled
+    spans = [shard_bounds(8_000_003, 8, r) for r in range(8)]
+    assert [b - a for a, b in spans] == [1_000_001] * 3 + [1_000_000] * 5 and spans[-1][1] == 8_000_003
+    for n in (2, 4, 8):
+        assert sum(b - a for a, b in (shard_bounds(8_000_000, n, r) for r in range(n))) == 8_000_000
+
+
 def test_result_block_is_one_buffer_of_fixed_stride():
     """limit x 12 B + 4 B per needle, rows and counts views of one allocation."""
     b = ResultBlock(7, 10)
