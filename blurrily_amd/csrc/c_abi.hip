@@ -129,7 +129,17 @@ struct trigram_map_t {
   int         last_tuned = -1;          // the class measured most recently ("tuned_*_us" report its figures)
   int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2 / 3; 0: none yet)
   size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
-  hipEvent_t  tune_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t  tune_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // a measured choice is WATCHED: the chosen sweep's later batches of the class are bracketed by two events (read at the
+  // class's next batch, never waited for); one that ran over 10 % slower per needle than what the measurement saw has
+  // the class measured again -- at most once in sixteen batches
+  hipEvent_t  watch_ev[6][2] = {};
+  bool        watch_pending[6] = {false, false, false, false, false, false};
+  size_t      watch_n[6] = {0, 0, 0, 0, 0, 0};
+  float       tuned_us_per_needle[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // of the sweep that was chosen
+  uint32_t    retune_holdoff[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t    retunes = 0;              // classes measured again because a batch ran slow (option "retunes", read-only)
+  int         tune_inject = 0;          // (tests) the next measurement sees this sweep at HALF its time: a bad sample to recover from
   int         n_cus = 0;
   bool        timing = false;
   bool        collect_stats = false;    // request counters of the find kernels (FindArgs::stats)
@@ -510,6 +520,21 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
                                 : leave_possible && ix.n_windows >= m->nm_min_windows ? 3 : 1;
       const int cls = (limit > 32 ? 3 : 0) + (n_cls < 65536 ? 0 : n_cls < 262144 ? 1 : 2);
       const bool tunable = m->ws_autotune && is_base && n_cls >= 16384 && (leave_possible || ws_possible);
+      // what the class's last batch took, if it has finished (never waited for): slow against the measurement?
+      if (tunable && !cb && m->watch_pending[cls] && hipEventQuery(m->watch_ev[cls][1]) == hipSuccess) {
+        float ms = 0.f;
+        m->watch_pending[cls] = false;
+        if (hipEventElapsedTime(&ms, m->watch_ev[cls][0], m->watch_ev[cls][1]) == hipSuccess && m->watch_n[cls] &&
+            m->tuned_us_per_needle[cls] > 0.f && m->ws_choice[cls] != 0) {
+          const float us = 1000.f * ms / float(m->watch_n[cls]);
+          if (us > 1.10f * m->tuned_us_per_needle[cls] && m->retune_holdoff[cls] == 0) {
+            m->ws_choice[cls] = 0;                     // measured again, below
+            m->retune_holdoff[cls] = 16;
+            ++m->retunes;
+          }
+        }
+      }
+      if (m->retune_holdoff[cls]) --m->retune_holdoff[cls];
       if (!tunable) {
         choice = static_choice;
       } else if (m->ws_choice[cls] != 0 && (m->ws_choice[cls] != 2 || ws_possible) && (m->ws_choice[cls] != 3 || leave_possible)) {
@@ -518,41 +543,58 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         choice = static_choice;                        // (counters must describe ONE sweep: an unmeasured class is not measured here)
       } else {
         if (!m->tune_ev[0]) {
-          hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+          hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
           for (auto& e : ev)
             if (hipEventCreate(&e) != hipSuccess) {
               for (auto& d : ev) if (d) (void)hipEventDestroy(d);
               errno = EIO;
               return -1;
             }
-          for (int i = 0; i < 5; ++i) m->tune_ev[i] = ev[i];
+          for (int i = 0; i < 7; ++i) m->tune_ev[i] = ev[i];
         }
-        const int order[4] = {1, leave_possible ? 3 : 0, ws_possible ? 2 : 0, 1};
-        float ms_of[4] = {0.f, 0.f, 0.f, 0.f};         // by sweep: [1] plain (the better of its two runs), [2], [3]
+        // every sweep the class can take, TWICE, the better run counting (the first run of all meets cold caches; one
+        // sample per sweep with a 1.5 % margin -- rounds 3 and 4 -- sat inside run-to-run noise); the plain sweep goes last,
+        // so that the rows in place are its
+        const int order[6] = {1, leave_possible ? 3 : 0, ws_possible ? 2 : 0, leave_possible ? 3 : 0, ws_possible ? 2 : 0, 1};
+        float ms_of[4] = {0.f, 0.f, 0.f, 0.f};         // by sweep: [1] plain, [2] window-major, [3] slices left out
         BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[0], stream));
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 6; ++k) {
           if (order[k] && run_sweep(order[k]) < 0) return -1;
           BLURRILY_HIP_TRY(hipEventRecord(m->tune_ev[k + 1], stream));
         }
-        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[4]));
-        for (int k = 0; k < 4; ++k) {
+        BLURRILY_HIP_TRY(hipEventSynchronize(m->tune_ev[6]));
+        for (int k = 0; k < 6; ++k) {
           if (!order[k]) continue;
           float ms = 0.f;
           BLURRILY_HIP_TRY(hipEventElapsedTime(&ms, m->tune_ev[k], m->tune_ev[k + 1]));
           ms_of[order[k]] = ms_of[order[k]] == 0.f ? ms : std::min(ms_of[order[k]], ms);
         }
+        if (m->tune_inject >= 1 && m->tune_inject <= 3) { ms_of[m->tune_inject] *= 0.5f; m->tune_inject = 0; }   // (tests)
         choice = 1;
         float best = ms_of[1];
-        if (leave_possible && ms_of[3] < 0.985f * ms_of[1]) { choice = 3; best = ms_of[3]; }
-        if (ws_possible && ms_of[2] < 0.95f * ms_of[1] && ms_of[2] < best) choice = 2;
+        if (leave_possible && ms_of[3] < 0.97f * ms_of[1]) { choice = 3; best = ms_of[3]; }
+        if (ws_possible && ms_of[2] < 0.95f * ms_of[1] && ms_of[2] < best) { choice = 2; best = ms_of[2]; }
         m->ws_choice[cls] = choice;
         m->ws_tuned_ms[cls][0] = ms_of[1]; m->ws_tuned_ms[cls][1] = ms_of[2]; m->ws_tuned_ms[cls][2] = ms_of[3];
+        m->tuned_us_per_needle[cls] = 1000.f * best / float(n);
+        m->watch_pending[cls] = false;
         m->last_tuned = cls;
         m->last_sweep = 1;                             // (the rows in place are the plain run's; all give the same)
         a.nm_cmin = 0;
         goto short_needles_done;
       }
+      const bool watch = tunable && !cb && m->ws_choice[cls] == choice && m->tuned_us_per_needle[cls] > 0.f;
+      if (watch) {
+        if (!m->watch_ev[cls][0])
+          for (auto& e : m->watch_ev[cls]) BLURRILY_HIP_TRY(hipEventCreate(&e));
+        BLURRILY_HIP_TRY(hipEventRecord(m->watch_ev[cls][0], stream));
+      }
       if (run_sweep(choice) < 0) return -1;
+      if (watch) {
+        BLURRILY_HIP_TRY(hipEventRecord(m->watch_ev[cls][1], stream));
+        m->watch_pending[cls] = true;
+        m->watch_n[cls] = n;
+      }
       if (is_base) m->last_sweep = choice;
       a.nm_cmin = 0;
     }
@@ -636,6 +678,7 @@ void free_replica(Replica& r) {
     s->ws_base_rows.release(); s->ws_base_counts.release(); s->ws_delta_rows.release(); s->ws_delta_counts.release();
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->tune_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& w : s->watch_ev) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     s->ws_codes.release(); s->ws_small.release(); s->ws_parts.release(); s->ws_flags.release(); s->ws_tomb.release();
     delete s;
   }
@@ -886,6 +929,7 @@ int blurrily_storage_close(trigram_map* haystack) {
     m->ws_base_rows.release(); m->ws_base_counts.release(); m->ws_delta_rows.release(); m->ws_delta_counts.release();
     for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : m->tune_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& w : m->watch_ev) for (auto& e : w) if (e) (void)hipEventDestroy(e);
     m->ws_codes.release(); m->ws_small.release(); m->ws_parts.release(); m->ws_io_in.release();
     m->ws_io_out.release(); m->ws_tomb.release(); m->ws_flags.release();
     if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -1390,7 +1434,8 @@ constexpr OptionSlot kMapOptions[] = {
     {"nm_cmin", 0, 64}, {"nm_dense", 64, 65536}, {"last_sweep", 0, 0}, {"devices", 1, 64},
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
     {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
-    {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20}};
+    {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20},
+    {"retunes", 0, 0}, {"tune_inject", 0, 3}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1437,6 +1482,8 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 21: m->one.enabled = value != 0; return 0;      // (the single find's own launch; nothing to measure again)
     case 22: return 0;                                   // (read-only)
     case 23: m->one.min_per = uint32_t(value); return 0;
+    case 24: return 0;                                   // (read-only)
+    case 25: m->tune_inject = int(value); return 0;      // (tests: the next measurement's bad sample)
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1480,6 +1527,8 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 21: *value = m->one.enabled; return 0;
     case 22: *value = (long long)m->one.taken; return 0;
     case 23: *value = m->one.min_per; return 0;
+    case 24: *value = (long long)m->retunes; return 0;
+    case 25: *value = m->tune_inject; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -284,7 +284,24 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
     mean_hit_slice = nnz ? sq / double(nnz) / double(n_win) : 0.0;
   }
   // dense: the PADDED length reaches dense_min8 -- what a kernel can tell from the slice table alone
-  const uint32_t dense_min8 = (std::max(64u, std::min(opt.dense_min, kWindowSize)) + 7u) & ~7u;
+  uint32_t dense_min8 = (std::max(64u, std::min(opt.dense_min, kWindowSize)) + 7u) & ~7u;
+  {
+    // The bitmaps live inline in `ent`, whose slots are numbered in 32 bits: a low "dense_min" on a large map would
+    // overflow that with bitmaps alone (8 KiB per dense slice).  Rather than fail every later find, the threshold is
+    // raised for THIS build until the image fits (said on stderr; past a window's size no slice is dense).
+    auto slots_with = [&](uint32_t dm8) {
+      uint64_t t = 0;
+      for (uint64_t i = 0; i < n_slices; ++i) {
+        const uint32_t len = (slice_off[i + 1] + 7u) & ~7u;
+        t += len + (len >= dm8 ? kBitmapSlots : 0u);
+      }
+      return t;
+    };
+    const uint32_t asked = dense_min8;
+    while (dense_min8 <= kWindowSize && slots_with(dense_min8) > 0xFFFF0000ull) dense_min8 *= 2;
+    if (dense_min8 != asked)
+      std::fprintf(stderr, "blurrily_hip: \"dense_min\" %u would put the image past 2^32 slots: %u for this build\n", asked, dense_min8);
+  }
   auto is_dense = [&](uint32_t len) { return ((len + 7u) & ~7u) >= dense_min8; };
   double dense_share = 0.0;
   {

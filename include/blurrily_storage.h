@@ -249,8 +249,12 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_autotune"     (1)     which sweep serves a class of batches (limit up to / above 32; 16 384.. / 65 536.. /
  *                             262 144.. needles) is MEASURED: the first such batch on an image runs every sweep it can
  *                             take -- needle-major, window-major, needle-major with dense slices left out of the count
- *                             -- (same rows; that one call waits for them, see blurrily_storage_tune) and the fastest
- *                             serves the class until the image is rebuilt or an option changes.  0: the static rules below
+ *                             -- TWICE, the better run counting (same rows; that one call waits for them, see
+ *                             blurrily_storage_tune) and the fastest serves the class until the image is rebuilt or an
+ *                             option changes; leaving slices out has to win by 3 %, the window-major sweep by 5 %.  The
+ *                             choice is watched: a later batch of the class that runs over 10 % slower per needle than
+ *                             the measurement saw has the class measured again, at most once in sixteen batches
+ *                             ("retunes", get: how often that happened).  0: the static rules below
  *   "ws_static_slice" (2200)  the static rule: window-major iff mean postings per window >= this, x1.7 for batches
  *                             under 65 536 needles, x1.7 for limits above 32, x4 for both (measured table)
  *   "ws_choice"       get: what has been measured (class c in bits 2c+1:2c: 0 not yet, 1 needle-major,
@@ -274,7 +278,9 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_min_needles"  (16384) smallest batch it is taken for
  *   "ws_cmin"         (3)     counted matches a left-out slice must leave
  *   "dense_min"       (1024)  postings from which a (window, trigram) slice also exists as a bitmap; changing
- *                             it rebuilds the device image at the next find
+ *                             it rebuilds the device image at the next find.  Bitmaps are part of the postings
+ *                             array (2^32 slots at most): a value that would overflow it is doubled for that build
+ *                             until the image fits (a line on stderr says so)
  *   "one_launch"      (1)     blurrily_storage_find as ONE launch without copies where it can be (see there); 0: always the
  *                             batch's way.  "one_taken" (get): finds served that way so far.  "one_windows_per_wg" (0): at
  *                             least this many windows per workgroup of that launch (0: as few as 256 workgroups allow)

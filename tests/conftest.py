@@ -34,3 +34,26 @@ def _built():
     """The suites need the built artefacts; build() is idempotent and quick when up to date."""
     import __graft_entry__ as g
     g.build()
+
+
+class _FullGeonames:
+    """configs[2]'s haystack (8 423 769 strings: tools/workloads.py bench_haystack("geonames")) ONCE per session, and the
+    oracle over it, built on first use -- two full-size tests check against it, and it is the one costly build of the suite."""
+
+    def __init__(self):
+        import workloads as W
+        self.hay, self.off = W.bench_haystack("geonames")
+        self._oracle = None
+
+    @property
+    def oracle(self):
+        if self._oracle is None:
+            from helpers import Oracle
+            self._oracle = Oracle()
+            self._oracle.put_many(self.hay, self.off)
+        return self._oracle
+
+
+@pytest.fixture(scope="session")
+def geonames_full():
+    return _FullGeonames()

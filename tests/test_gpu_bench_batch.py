@@ -44,11 +44,11 @@ def _order_ok(rows, counts, limit):
 
 
 @pytest.mark.parametrize("name,n_sample,per_class", [("geonames", 1200, 150), ("words", 3000, 0), ("skewed", 300, 0)])
-def test_the_benched_call_on_the_benched_batch(name, n_sample, per_class):
+def test_the_benched_call_on_the_benched_batch(name, n_sample, per_class, geonames_full):
     import torch
     spec = W.BENCH_WORKLOADS[name]
     limit = spec["limit"]
-    hay, off = W.bench_haystack(name)
+    hay, off = (geonames_full.hay, geonames_full.off) if name == "geonames" else W.bench_haystack(name)
     n = len(off) - 1
     qp, qo = W.bench_needles(hay, off, name)
     n_q = len(qo) - 1
@@ -74,8 +74,11 @@ def test_the_benched_call_on_the_benched_batch(name, n_sample, per_class):
     counts = d_counts.cpu().numpy().view(np.uint32).astype(np.int64)
     nb = d_nb.cpu().numpy().view(np.uint32).astype(np.uint64)
 
-    o = Oracle()
-    o.put_many(hay, off)
+    if name == "geonames":
+        o = geonames_full.oracle                                   # (the session's: tests/conftest.py)
+    else:
+        o = Oracle()
+        o.put_many(hay, off)
     every = o.batch(qp, qo, find=False, nb=True, ntri=True)
 
     # ---- all needles ---------------------------------------------------------------------

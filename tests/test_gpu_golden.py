@@ -59,11 +59,12 @@ def test_hip_vs_live_reference(kind, n, limit):
         ref.close()
 
 
-def test_full_geonames_scale_properties():
+def test_full_geonames_scale_properties(geonames_full):
     """configs[2] haystack (8 423 769 strings): properties that need no full-size checker, and a
     sample of needles checked row for row against the oracle."""
     n = 8423769
-    hay, off = W.geonames(n, 500000, 3)
+    hay, off = geonames_full.hay, geonames_full.off
+    assert len(off) - 1 == n
     m = RawMap()
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
     rng = np.random.default_rng(1)
@@ -87,8 +88,7 @@ def test_full_geonames_scale_properties():
         keys = [(-r[1], r[2], r[0]) for r in rows]
         assert rows[0][1] == T                                     # nothing can match more than T trigrams
         assert own in keys or (len(keys) == limit and max(keys) < own)
-    o = Oracle()
-    o.put_many(hay, off)
+    o = geonames_full.oracle
     for nd, rows in list(zip(needles, got))[1990:2030]:
         assert rows == o.find(nd, limit), nd
 

@@ -34,9 +34,24 @@ print("ok")
 """
 
 
+HEADS = {"blurrily": "from blurrily_amd import RawMap, _native\n_native.lib()\nimport torch\n",
+         "torch": "import torch\nfrom blurrily_amd import RawMap, _native\n"}
+
+
+@pytest.fixture(scope="module")
+def interpreters():
+    """both orders, each in its own interpreter -- STARTED TOGETHER: a fresh interpreter's `import torch` is most of a
+    minute on a fresh box, and the two do not depend on each other"""
+    procs = {k: subprocess.Popen([sys.executable, "-c", h + BODY], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k, h in HEADS.items()}
+    yield procs
+    for p in procs.values():
+        if p.poll() is None:
+            p.kill()
+
+
 @pytest.mark.parametrize("first", ["blurrily", "torch"])
-def test_import_order(first):
-    head = ("from blurrily_amd import RawMap, _native\n_native.lib()\nimport torch\n" if first == "blurrily"
-            else "import torch\nfrom blurrily_amd import RawMap, _native\n")
-    r = subprocess.run([sys.executable, "-c", head + BODY], cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+def test_import_order(first, interpreters):
+    p = interpreters[first]
+    out, err = p.communicate(timeout=400)
+    assert p.returncode == 0 and out.strip().endswith("ok"), out + err
