@@ -3086,9 +3086,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   __shared__ unsigned long long s_pool[kWsPool];
   __shared__ Control s_ctl;
   __shared__ uint32_t s_tally[8];                        // the cold start's tallies, one per pass of the search
-  __shared__ uint32_t s_nextq;
+  __shared__ uint32_t s_nextq[2];                        // the queue slot popped for the needle after the current one, by that needle's parity
   __shared__ uint32_t s_cand[kSmallCand];                // a window's counters at the bound: in-window rank | count << 16
-  __shared__ uint32_t s_ncand;                           // the queue slot popped for the needle after the current one
+  __shared__ uint32_t s_ncand;
   uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
   Control* ctl = &s_ctl;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -3108,6 +3108,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   constexpr uint32_t kSmallChunk = 4;
   uint32_t ch_base = 0, ch_left = 0;                     // (thread 0: what is left of the slots it took last)
   uint32_t stage = 0, nx_pop = 0, nx_q = 0, nx_T = 0, nx_nb = 0, nx_qs = 0, nx_code = 0;
+  uint32_t nx_par = 0;                                   // (two slots by turns: a needle that is skipped at once -- too long, empty -- has
+                                                         //  thread 0 writing the NEXT needle's slot while slow waves still read this one's)
   uint64_t nx_off = 0;
   bool nx_ok = false;
   uint2 nx_se = make_uint2(0, 0);
@@ -3115,15 +3117,16 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   do {                                                                                    \
     switch (stage) {                                                                      \
       case 0:                                                                             \
+        nx_par ^= 1u;                                                                     \
         if (tid == 0) {                    /* (slots are taken kSmallChunk at a time: see above) */ \
           if (ch_left == 0) { ch_base = atomicAdd(A.queue, kSmallChunk); ch_left = kSmallChunk; } \
           nx_pop = ch_base++; --ch_left;                                                  \
         }                                                                                 \
         stage = 1; break;                                                                 \
-      case 1: if (tid == 0) s_nextq = nx_pop; stage = 2; break;                           \
+      case 1: if (tid == 0) s_nextq[nx_par] = nx_pop; stage = 2; break;                   \
       case 2:                                                                             \
         ws_barrier();                                                                     \
-        nx_q = s_nextq;                                                                   \
+        nx_q = s_nextq[nx_par];                                                           \
         nx_ok = nx_q < A.n_work;                                                          \
         if (nx_ok) { nx_T = A.q_ntri[nx_q]; nx_nb = A.q_nb[nx_q]; nx_off = A.offsets[nx_q]; nx_qs = A.q_start[nx_q]; } \
         stage = 3; break;                                                                 \

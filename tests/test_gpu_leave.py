@@ -70,7 +70,7 @@ def _mixed(hay, off, n_q, seed):
 def medium():
     hay, off = W.geonames(700000, 90000, 51)                   # 11 windows
     m, o = _pair(hay, off, dense_min=256, nm_cmin=3, nm_dense=256)
-    q, qo = _mixed(hay, off, 9000, 52)
+    q, qo = _mixed(hay, off, 4000, 52)
     yield m, o, q, qo
     m.close()
 
