@@ -155,9 +155,9 @@ struct trigram_map_t {
   // sequence word into, the per-workgroup lists and the ticket on the device
   struct One {
     hipStream_t    stream = nullptr;
-    unsigned char* h_out = nullptr;     // [kOneMaxKeep rows | count | sequence word]
+    unsigned char* h_out = nullptr;     // [kOneMaxNeedles][kOneMaxKeep] rows | [kOneMaxNeedles][2] count, sequence word
     unsigned char* d_out = nullptr;     // the same memory as the device addresses it
-    DeviceBuffer   d_parts;             // [kOneMaxGrid * kOneMaxKeep keys | kOneMaxGrid flags]
+    DeviceBuffer   d_parts;             // [kOneMaxNeedles][kOneMaxGrid * kOneMaxKeep] keys | [kOneMaxNeedles][kOneMaxGrid] flags
     uint32_t       seq = 0;
     bool           enabled = true;      // option "one_launch"
     uint32_t       min_per = 0;         // option "one_windows_per_wg": at least this many windows per workgroup (0: as few as the grid allows)
@@ -1138,11 +1138,28 @@ static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t*
   return rc;
 }
 
+// (a handful of needles share one launch: find_few, below)
+constexpr int kOneNotTaken = -2;
+static int find_few(trigram_map m, const char* const* s, const size_t* len, size_t n, uint16_t limit, trigram_match results,
+                    uint32_t* counts);
+
 // Host-buffer batch: needles in, rows out.  raw = the needles are un-normalised ASCII (see
 // blurrily_storage_find_batch_raw); non_ascii (raw only, may be null) receives the per-needle flags.
 static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                            trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii) {
   if (n == 0) return 0;
+  if (!raw && n <= kOneMaxNeedles) {                  // a handful of needles: they share ONE launch (find_few)
+    const char* s[kOneMaxNeedles];
+    size_t len[kOneMaxNeedles];
+    for (size_t i = 0; i < n; ++i) {
+      s[i] = packed + offsets[i];
+      const size_t cap = size_t(offsets[i + 1] - offsets[i]);
+      const void* nul = std::memchr(s[i], 0, cap);
+      len[i] = nul ? size_t(static_cast<const char*>(nul) - s[i]) : cap;
+    }
+    const int few = find_few(m, s, len, n, limit, results, counts);
+    if (few != kOneNotTaken) return few;
+  }
   DeviceScope scope(m->dev.device);
   // what the reference's find does first: tokenise, sort the needle's dirty buckets
   size_t max_len = 0;
@@ -1228,30 +1245,50 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
   return 0;
 }
 
-// ---- ONE needle, the caller waiting: one launch, no copies (find_kernels.hip: find_one_kernel) ---------------------
-// The reference's only call shape (ext/blurrily/map_ext.c:131-162 -> storage.c:477-580).  Returns the number of rows,
-// -1 with errno, or kOneNotTaken when the find has to go the batch's way: a limit of 0 or above kOneMaxKeep, a needle
-// of more than 64 distinct trigrams, mutations the base image does not hold yet (tombstones, pending puts), timing or
-// request counters switched on, option "one_launch" 0.
-constexpr int kOneNotTaken = -2;
-constexpr size_t kOneHostBytes = kOneMaxKeep * sizeof(trigram_match_t) + 64;
+// ---- ONE needle, the caller waiting -- or a handful: one launch, no copies (find_kernels.hip: find_one_kernel) --------
+// The reference's only call shape (ext/blurrily/map_ext.c:131-162 -> storage.c:477-580), and small host-buffer batches
+// (a server's coalesced FINDs under light load).  needle i = s[i][0 .. len[i]) (up to its first NUL).  Returns 0 with
+// counts[] and rows filled (results + i * limit), -1 with errno, or kOneNotTaken when the finds have to go the batch's
+// way: a limit of 0 or above kOneMaxKeep, more than kOneMaxNeedles needles, a needle of more than 64 distinct trigrams,
+// mutations the base image does not hold yet (tombstones, pending puts), timing or request counters switched on,
+// option "one_launch" 0.
+constexpr size_t kOneRowBytes = kOneMaxKeep * sizeof(trigram_match_t);
+constexpr size_t kOneHostBytes = kOneMaxNeedles * (kOneRowBytes + 8) + 64;
 
-static int find_one(trigram_map m, const char* needle, uint16_t limit, trigram_match results) {
-  if (!m->one.enabled || limit == 0 || limit > kOneMaxKeep || m->timing || m->collect_stats) return kOneNotTaken;
-  const size_t len = std::strlen(needle);
-  if (len > 255) return kOneNotTaken;
-  uint16_t codes[256];
-  const int T = tokenise(needle, len, codes);             // tokeniser.c:59-119
-  if (T > 64) return kOneNotTaken;
+static int find_few(trigram_map m, const char* const* s, const size_t* len, size_t n, uint16_t limit, trigram_match results,
+                    uint32_t* counts) {
+  if (!m->one.enabled || limit == 0 || limit > kOneMaxKeep || n == 0 || n > kOneMaxNeedles || m->timing || m->collect_stats)
+    return kOneNotTaken;
+  uint16_t codes[kOneMaxNeedles * 64];
+  uint32_t T[kOneMaxNeedles];
+  {
+    uint16_t buf[256];
+    for (size_t i = 0; i < n; ++i) {
+      if (len[i] > 255) return kOneNotTaken;
+      const int t = tokenise(s[i], len[i], buf);            // tokeniser.c:59-119
+      if (t > 64) return kOneNotTaken;
+      T[i] = uint32_t(t);
+      std::memcpy(codes + i * 64, buf, size_t(t) * sizeof(uint16_t));
+    }
+  }
   DeviceScope scope(m->dev.device);
   // what the reference's find does first: sort the needle's dirty buckets (storage.c:516), sum their sizes (:498-503)
   if (m->host->dirty_buckets())
-    for (int k = 0; k < T; ++k) m->host->sort_bucket_if_dirty(codes[k]);
+    for (size_t i = 0; i < n; ++i)
+      for (uint32_t k = 0; k < T[i]; ++k) m->host->sort_bucket_if_dirty(codes[i * 64 + k]);
   if (ensure_device(m) < 0) return -1;
   if (!log_empty(m)) return kOneNotTaken;
-  uint64_t nb = 0;
-  for (int k = 0; k < T; ++k) nb += m->host->bucket(codes[k]).used;
-  if (nb == 0) return 0;                                  // storage.c:503
+  // needles without a posting return no rows (storage.c:503) and take no row of the grid
+  uint32_t row_of[kOneMaxNeedles], n_rows = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t nb = 0;
+    for (uint32_t k = 0; k < T[i]; ++k) nb += m->host->bucket(codes[i * 64 + k]).used;
+    counts[i] = 0;
+    if (nb == 0) continue;
+    if (n_rows != i) { std::memmove(codes + n_rows * 64, codes + i * 64, 64 * sizeof(uint16_t)); T[n_rows] = T[i]; }
+    row_of[n_rows++] = uint32_t(i);
+  }
+  if (n_rows == 0) return 0;
   auto& O = m->one;
   if (!O.stream) {
     BLURRILY_HIP_TRY(hipStreamCreateWithFlags(&O.stream, hipStreamNonBlocking));
@@ -1260,10 +1297,10 @@ static int find_one(trigram_map m, const char* needle, uint16_t limit, trigram_m
     std::memset(O.h_out, 0, kOneHostBytes);
     BLURRILY_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&O.d_out), O.h_out, 0));
   }
-  const size_t key_bytes = size_t(kOneMaxGrid) * kOneMaxKeep * 8;
+  const size_t key_bytes = size_t(kOneMaxNeedles) * kOneMaxGrid * kOneMaxKeep * 8, flag_bytes = size_t(kOneMaxNeedles) * kOneMaxGrid * 4;
   if (!O.d_parts.p) {
-    if (O.d_parts.reserve(key_bytes + kOneMaxGrid * 4, O.stream) < 0) return -1;
-    BLURRILY_HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(O.d_parts.p) + key_bytes, 0, kOneMaxGrid * 4, O.stream));
+    if (O.d_parts.reserve(key_bytes + flag_bytes, O.stream) < 0) return -1;
+    BLURRILY_HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(O.d_parts.p) + key_bytes, 0, flag_bytes, O.stream));
   }
   const DeviceIndex& ix = m->dev;
   FindArgs a{};
@@ -1281,32 +1318,37 @@ static int find_one(trigram_map m, const char* needle, uint16_t limit, trigram_m
   per = std::max(per, O.min_per);                         // (a test's way to the several-steps-per-workgroup path on a small image)
   const uint32_t grid = (ix.n_windows + per - 1) / per;
   unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p);
-  const uint32_t seq = ++O.seq ? O.seq : ++O.seq;         // (never 0: what the word holds before the first find)
-  volatile uint32_t* h_words = reinterpret_cast<volatile uint32_t*>(O.h_out + kOneMaxKeep * sizeof(trigram_match_t));
-  if (launch_find_one(a, codes, uint32_t(T), per, grid, reinterpret_cast<unsigned long long*>(dp),
-                      reinterpret_cast<uint32_t*>(dp + key_bytes),
-                      reinterpret_cast<trigram_match_t*>(O.d_out),
-                      reinterpret_cast<uint32_t*>(O.d_out + kOneMaxKeep * sizeof(trigram_match_t)), seq, O.stream) < 0)
+  const uint32_t seq = ++O.seq ? O.seq : ++O.seq;         // (never 0: what the words hold before the first find)
+  unsigned char* h_words = O.h_out + kOneMaxNeedles * kOneRowBytes;     // [needle][2]: rows, sequence word
+  unsigned char* d_words = O.d_out + kOneMaxNeedles * kOneRowBytes;
+  if (launch_find_one(a, codes, T, n_rows, per, grid, reinterpret_cast<unsigned long long*>(dp),
+                      reinterpret_cast<uint32_t*>(dp + key_bytes), reinterpret_cast<trigram_match_t*>(O.d_out),
+                      reinterpret_cast<uint32_t*>(d_words), seq, O.stream) < 0)
     return -1;
-  // The kernel's last store is the sequence word; the host polls it in the pinned page instead of waiting for the
+  // A row's last store is its sequence word; the host polls the words in the pinned page instead of waiting for the
   // runtime to notice the kernel's completion signal (an interrupt or a slower poll: 10 us and more).
+  volatile uint32_t* words = reinterpret_cast<volatile uint32_t*>(h_words);
   uint64_t spins = 0;
-  while (h_words[1] != seq) {
+  for (uint32_t r = 0; r < n_rows; ++r) {
+    while (words[2 * r + 1] != seq) {
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+      __builtin_ia32_pause();
 #endif
-    if ((++spins & 0xFFFFFu) == 0) {                      // every few milliseconds: is the stream still alive?
-      const hipError_t q = hipStreamQuery(O.stream);
-      if (q == hipSuccess && h_words[1] != seq) { std::fprintf(stderr, "blurrily_hip: find_one finished without its rows\n"); errno = EIO; return -1; }
-      if (q != hipSuccess && q != hipErrorNotReady) { std::fprintf(stderr, "blurrily_hip: find_one: %s\n", hipGetErrorString(q)); errno = EIO; return -1; }
+      if ((++spins & 0xFFFFFu) == 0) {                    // every few milliseconds: is the stream still alive?
+        const hipError_t q = hipStreamQuery(O.stream);
+        if (q == hipSuccess && words[2 * r + 1] != seq) { std::fprintf(stderr, "blurrily_hip: find_one finished without its rows\n"); errno = EIO; return -1; }
+        if (q != hipSuccess && q != hipErrorNotReady) { std::fprintf(stderr, "blurrily_hip: find_one: %s\n", hipGetErrorString(q)); errno = EIO; return -1; }
+      }
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  const uint32_t n_rows = h_words[0];
-  const uint32_t count = n_rows < limit ? n_rows : uint32_t(limit);
-  std::memcpy(results, O.h_out, size_t(count) * sizeof(trigram_match_t));
-  ++O.taken;
-  return int(count);
+  for (uint32_t r = 0; r < n_rows; ++r) {
+    const uint32_t got = words[2 * r], i = row_of[r];
+    counts[i] = got < limit ? got : uint32_t(limit);
+    std::memcpy(results + size_t(i) * limit, O.h_out + r * kOneRowBytes, size_t(counts[i]) * sizeof(trigram_match_t));
+  }
+  O.taken += n_rows;
+  return 0;
 }
 
 extern "C" {
@@ -1335,8 +1377,12 @@ int blurrily_normalize_batch_device(const char* d_packed, const uint64_t* d_offs
 }
 
 int blurrily_storage_find(trigram_map haystack, const char* needle, uint16_t limit, trigram_match results) {
-  const int one = find_one(haystack, needle, limit, results);
-  if (one != kOneNotTaken) return one;
+  {
+    const size_t len = std::strlen(needle);
+    uint32_t n_rows = 0;
+    const int one = find_few(haystack, &needle, &len, 1, limit, results, &n_rows);
+    if (one != kOneNotTaken) return one < 0 ? one : int(n_rows);
+  }
   const uint64_t offsets[2] = {0, std::strlen(needle)};
   uint32_t count = 0;
   // the device writes `limit` rows per needle; go through a scratch so a short

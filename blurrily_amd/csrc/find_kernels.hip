@@ -3660,13 +3660,13 @@ __device__ __forceinline__ void one_step(const FindArgs& A, const uint32_t T, co
 }
 
 struct OneArgs {
-  uint16_t codes[64];            // the needle's distinct trigram codes, ascending (tokeniser.c:59-119, by the host)
-  uint32_t T;                    // how many
+  uint16_t codes[kOneMaxNeedles][64];   // a needle's distinct trigram codes, ascending (tokeniser.c:59-119, by the host)
+  uint32_t T[kOneMaxNeedles];           // how many
   uint32_t per;                  // windows per workgroup
-  unsigned long long* part_keys; // [grid * keep]: a workgroup's best keys ascending, padded with kKeyInf
-  uint32_t* flags;               // [grid] workgroup g's list is complete: the launch's sequence word
-  trigram_match_t* out_rows;     // host-coherent pinned memory: [keep]
-  uint32_t* out_count;           //   ... [0] = rows, [1] = the sequence word, written last
+  unsigned long long* part_keys; // [needle][grid.x * keep]: a workgroup's best keys ascending, padded with kKeyInf
+  uint32_t* flags;               // [needle][grid.x] workgroup g's list is complete: the launch's sequence word
+  trigram_match_t* out_rows;     // host-coherent pinned memory: [needle][kOneMaxKeep]
+  uint32_t* out_count;           //   ... [needle][2]: rows, the sequence word (written last)
   uint32_t seq;
 };
 
@@ -3681,14 +3681,20 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t g = blockIdx.x, G = gridDim.x;
   ONE_MARK(A, 0);
+  // a row of the grid per needle (a handful of needles share the launch: blockIdx.y); its lists, flags and rows
+  const uint32_t nd_i = blockIdx.y;
+  const uint32_t T = O.T[nd_i];
+  unsigned long long* const part_keys = O.part_keys + size_t(nd_i) * G * A.keep;
+  uint32_t* const flags = O.flags + size_t(nd_i) * G;
+  trigram_match_t* const out_rows = O.out_rows + size_t(nd_i) * kOneMaxKeep;
+  uint32_t* const out_count = O.out_count + 2 * nd_i;
   // the needle's codes: lane t = trigram t (a load from the kernel-argument segment)
-  const uint32_t code = lane < O.T ? O.codes[lane] : 0u;
+  const uint32_t code = lane < T ? O.codes[nd_i][lane] : 0u;
   for (uint32_t i = tid; i < kWindowSize / 16; i += NT) cnt128[i] = make_uint4(0, 0, 0, 0);
   if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; ctl->pend_n[0] = 0; ctl->pend_n[1] = 0; }
   if (tid < 12) s_sh.tally[tid] = 0;
   __syncthreads();
   ONE_MARK(A, 1);
-  const uint32_t T = O.T;
   const uint32_t w0 = g * O.per, w1 = min(A.n_windows, w0 + O.per);
   for (uint32_t w = w0; w < w1;) {
     // 4-bit counters, both windows of a pair per step: any window for a needle of at most 15 trigrams, and for ANY
@@ -3715,18 +3721,18 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
   const uint32_t keep = A.keep;
   if (g != G - 1) {
     for (uint32_t i = tid; i < keep; i += NT)
-      __hip_atomic_store(&O.part_keys[size_t(g) * keep + i], i < nres ? s_pool[i] : kKeyInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&part_keys[size_t(g) * keep + i], i < nres ? s_pool[i] : kKeyInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ONE_MARK(A, 8);
-    if (tid == 0) __hip_atomic_store(&O.flags[g], O.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&flags[g], O.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   ONE_MARK(A, 8);
   {
     uint32_t pending;
     do {                                                 // lanes 0..G-2 of the first waves watch one flag each
-      const uint32_t f = tid < G - 1 ? __hip_atomic_load(&O.flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : O.seq;
+      const uint32_t f = tid < G - 1 ? __hip_atomic_load(&flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : O.seq;
       pending = __syncthreads_or(f != O.seq);
     } while (pending);
   }
@@ -3751,10 +3757,10 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
   for (uint32_t j = 0; j < kPerThread; ++j) {
     const uint32_t idx = tid + j * NT;
     mine[j] = kKeyInf;
-    if (idx < own0) mine[j] = __hip_atomic_load(&O.part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (idx < own0) mine[j] = __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   unsigned long long head = kKeyInf;
-  if (tid < g) head = __hip_atomic_load(&O.part_keys[size_t(tid) * keep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < g) head = __hip_atomic_load(&part_keys[size_t(tid) * keep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long own_key = kKeyInf;
   if (tid < nres) own_key = s_pool[tid];                  // (before s_pool becomes the heads' array)
   __syncthreads();
@@ -3789,7 +3795,7 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
 #pragma unroll
     for (uint32_t j = 0; j < kPerThread; ++j) {
       const uint32_t idx = base + tid + j * NT;
-      mine[j] = idx < own0 ? __hip_atomic_load(&O.part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKeyInf;
+      mine[j] = idx < own0 ? __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKeyInf;
     }
 #pragma unroll
     for (uint32_t j = 0; j < kPerThread; ++j) pass(mine[j], base + tid + j * NT);
@@ -3807,14 +3813,14 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
     row.reference = A.ref_of_rank[rk];
     row.matches = T - uint32_t(key >> 32);
     row.weight = A.weight_of_rank[rk];
-    O.out_rows[tid] = row;
+    out_rows[tid] = row;
   }
-  if (tid == 0) O.out_count[0] = n_out;
+  if (tid == 0) out_count[0] = n_out;
   ONE_MARK(A, 13);
   if (tid < ((n_out + 63u) & ~63u) || tid < 64) __threadfence_system();   // rows and count are in host memory before the sequence word
   __syncthreads();
   ONE_MARK(A, 14);
-  if (tid == 0) __hip_atomic_store(&O.out_count[1], O.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store(&out_count[1], O.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // keys -> rows, in place: a needle's keys occupy the first 8 bytes of every 12-byte row slot's
@@ -3978,22 +3984,24 @@ int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream) {
   return 0;
 }
 
-int launch_find_one(const FindArgs& a, const uint16_t* codes, uint32_t T, uint32_t per, uint32_t grid,
+int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T, uint32_t n_needles, uint32_t per, uint32_t grid,
                     unsigned long long* part_keys, uint32_t* flags, trigram_match_t* out_rows,
                     uint32_t* out_count, uint32_t seq, hipStream_t stream) {
   OneArgs o;
-  for (uint32_t t = 0; t < 64; ++t) o.codes[t] = t < T ? codes[t] : uint16_t(0);
-  o.T = T; o.per = per; o.part_keys = part_keys; o.flags = flags;
+  for (uint32_t i = 0; i < kOneMaxNeedles; ++i) {
+    o.T[i] = i < n_needles ? T[i] : 0u;
+    for (uint32_t t = 0; t < 64; ++t) o.codes[i][t] = i < n_needles && t < T[i] ? codes[i * 64 + t] : uint16_t(0);
+  }
+  o.per = per; o.part_keys = part_keys; o.flags = flags;
   o.out_rows = out_rows; o.out_count = out_count; o.seq = seq;
-  // (a workgroup has its CU to itself: with 69 KiB of LDS two of them fit a CU, and the one that is still counting
-  // then waits -- 27 us, measured -- while the other's waves sit in their serial sections; 24 KiB of dynamic LDS
-  // nobody touches keep the second workgroup off the CU: the grid never exceeds the CUs of the chip)
+  // ONE needle: its workgroups have their CUs to themselves (24 KiB of dynamic LDS nobody touches keep a second one off:
+  // the configuration the 31 us were measured in); a handful of needles fill the chip twice over: two per CU
   constexpr size_t kOneAloneLds = 24 * 1024;
   static std::atomic<uint64_t> attr_done{0};
   if (first_launch_on_this_device(attr_done))
     BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_one_kernel<kOneThreads>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(kOneAloneLds)));
-  hipLaunchKernelGGL((find_one_kernel<kOneThreads>), dim3(grid), dim3(kOneThreads), kOneAloneLds, stream, a, o);
+  hipLaunchKernelGGL((find_one_kernel<kOneThreads>), dim3(grid, n_needles), dim3(kOneThreads), n_needles == 1 ? kOneAloneLds : 0, stream, a, o);
   BLURRILY_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -156,3 +156,27 @@ def test_what_goes_the_batchs_way_instead(geo):
     m.set_timing(True)
     assert goes_one(nd, 10) == 0
     m.set_timing(False)
+
+
+def test_a_handful_of_needles_share_one_launch(geo):
+    """blurrily_storage_find_batch with up to sixteen needles: one launch, a row of the grid per needle (c_abi.hip:
+    find_few) -- each element still exactly one blurrily_storage_find; needles without a posting take no row; the
+    seventeenth needle sends the batch the old way."""
+    m, chk, strings = geo
+    rng = np.random.default_rng(8)
+    for n, limit in [(2, 10), (5, 1), (16, 10), (16, 120), (9, 64), (17, 10), (3, 121)]:
+        picks = [strings[int(k)] for k in rng.integers(0, len(strings), size=n)]
+        needles = [p[: max(1, len(p) - 1)] for p in picks]
+        if n >= 5:
+            needles[1] = b""                                   # no posting: no rows, no row of the grid
+            needles[3] = b"qqqqzzzzxxxx"
+        packed, off = _pack(needles)
+        taken = m.get_option("one_taken")
+        rows, counts = m.find_batch_packed(packed, off, limit)
+        went = m.get_option("one_taken") - taken
+        for i, nd in enumerate(needles):
+            assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (n, limit, nd)
+        if n <= 16 and limit <= 120:
+            assert went == sum(1 for nd in needles if chk.find(nd, 1))    # one row per needle that has any posting ...
+        else:
+            assert went == 0                                   # ... and none when the batch goes the old way
