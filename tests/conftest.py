@@ -57,3 +57,32 @@ class _FullGeonames:
 @pytest.fixture(scope="session")
 def geonames_full():
     return _FullGeonames()
+
+
+def two_ranks_command(port):
+    """bench.py's N > 1 path as two ranks sharing this box's GPU over gloo (tests/test_gpu_bench_batch.py:
+    test_bench_two_ranks_plumbing)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+            "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"]
+
+
+def pytest_collection_modifyitems(config, items):
+    """That run is a minute of two fresh interpreters importing torch: started when the session starts, it overlaps the
+    first tests instead of standing in the driver's clock; the test collects it (a plumbing test: nothing in it, or in
+    the tests it overlaps, asserts on a time)."""
+    if not any(it.name == "test_bench_two_ranks_plumbing" for it in items) or not _gpu_available():
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BLURRILY_DIST_BACKEND="gloo")
+    try:
+        import __graft_entry__ as g
+        g.build()                                            # (the ranks load the built library)
+        config._two_ranks = subprocess.Popen(two_ranks_command(port), env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                             stderr=subprocess.PIPE, text=True)
+    except Exception:
+        config._two_ranks = None

@@ -163,7 +163,7 @@ def test_the_benched_call_on_the_benched_batch(name, n_sample, per_class, geonam
     assert np.array_equal(np.where(live_s[:, :, None], h_rows, 0), np.where(live_s[:, :, None], rows[lo:hi], 0))
 
 
-def test_bench_two_ranks_plumbing(tmp_path):
+def test_bench_two_ranks_plumbing(tmp_path, request):
     """bench.py's N > 1 path end to end -- per-rank shards, ONE gather of the result blocks, max-over-ranks
     timing, the JSON line's per-rank fields -- as two ranks sharing this box's GPU, the blocks gathered
     through host memory over gloo (BLURRILY_DIST_BACKEND; RCCL needs a GPU per rank).  A plumbing test,
@@ -178,12 +178,18 @@ def test_bench_two_ranks_plumbing(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, BLURRILY_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"]
-    res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    started = getattr(request.config, "_two_ranks", None)      # (tests/conftest.py starts it with the session)
+    if started is not None:
+        out, err = started.communicate(timeout=600)
+        request.config._two_ranks = None
+        assert started.returncode == 0, err[-2000:]
+    else:
+        from conftest import two_ranks_command
+        res = subprocess.run(two_ranks_command(port), env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = res.stdout
+    line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     # n_gpus counts PHYSICAL devices (two ranks on this box's one GPU are one GPU); `replicas` the shards
     import torch

@@ -126,7 +126,7 @@ def test_tombstones_and_pending_puts_under_the_window_major_sweep():
     rng = np.random.default_rng(51)
     # delete the best match of many needles (tombstones on the base image), add new strings (delta image)
     rows, counts = m.find_batch_packed(q, qo, 10)
-    victims = sorted({int(rows[i, 0, 0]) for i in rng.choice(len(needles), size=1500, replace=False) if counts[i]})
+    victims = sorted({int(rows[i, 0, 0]) for i in rng.choice(len(needles), size=600, replace=False) if counts[i]})
     for ref in victims:
         assert m.delete(ref) == o.delete(ref)
     n = len(off) - 1
