@@ -84,7 +84,7 @@ def test_hot_trigrams_floods_of_ties_and_eight_windows():
     m, o = _pair(hay, off)
     m.sync_device()
     assert m.device_info()["n_windows"] == 8
-    q, qo = W.queries(hay, off, 3000, 64)
+    q, qo = W.queries(hay, off, 4500, 64)
     for limit in (10, 64):
         flags = _check(m, o, q, qo, limit)
         assert (flags & RESWEEP).any()
