@@ -1250,8 +1250,8 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
 // (a server's coalesced FINDs under light load).  needle i = s[i][0 .. len[i]) (up to its first NUL).  Returns 0 with
 // counts[] and rows filled (results + i * limit), -1 with errno, or kOneNotTaken when the finds have to go the batch's
 // way: a limit of 0 or above kOneMaxKeep, more than kOneMaxNeedles needles, a needle of more than 64 distinct trigrams,
-// mutations the base image does not hold yet (tombstones, pending puts), timing or request counters switched on,
-// option "one_launch" 0.
+// timing or request counters switched on, option "one_launch" 0.  Mutations the base image does not hold yet are
+// served: tombstones inside the select, pending puts by a second launch over the delta image.
 constexpr size_t kOneRowBytes = kOneMaxKeep * sizeof(trigram_match_t);
 constexpr size_t kOneHostBytes = kOneMaxNeedles * (kOneRowBytes + 8) + 64;
 
@@ -1277,7 +1277,10 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     for (size_t i = 0; i < n; ++i)
       for (uint32_t k = 0; k < T[i]; ++k) m->host->sort_bucket_if_dirty(codes[i * 64 + k]);
   if (ensure_device(m) < 0) return -1;
-  if (!log_empty(m)) return kOneNotTaken;
+  // Mutations the base image does not hold (DESIGN.md "Mutation and device sync"): deletes are tombstone bits the select
+  // looks at, pending puts live in a small delta image searched by a SECOND launch; the two lists of a needle are
+  // merged here (they hold disjoint references).  A log that has overflowed is folded by ensure_device above.
+  const bool with_tomb = log_of(m)->n_tomb != 0, with_delta = !log_of(m)->pending.empty() && m->delta.device >= 0;
   // needles without a posting return no rows (storage.c:503) and take no row of the grid
   uint32_t row_of[kOneMaxNeedles], n_rows = 0;
   for (size_t i = 0; i < n; ++i) {
@@ -1292,60 +1295,89 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   auto& O = m->one;
   if (!O.stream) {
     BLURRILY_HIP_TRY(hipStreamCreateWithFlags(&O.stream, hipStreamNonBlocking));
-    BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&O.h_out), kOneHostBytes,
+    BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&O.h_out), 2 * kOneHostBytes,
                                    hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(O.h_out, 0, kOneHostBytes);
+    std::memset(O.h_out, 0, 2 * kOneHostBytes);
     BLURRILY_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&O.d_out), O.h_out, 0));
   }
+  if (with_tomb && apply_tombstones(m, O.stream) < 0) return -1;       // (deletes since the last find: their bits are set first)
   const size_t key_bytes = size_t(kOneMaxNeedles) * kOneMaxGrid * kOneMaxKeep * 8, flag_bytes = size_t(kOneMaxNeedles) * kOneMaxGrid * 4;
   if (!O.d_parts.p) {
-    if (O.d_parts.reserve(key_bytes + flag_bytes, O.stream) < 0) return -1;
-    BLURRILY_HIP_TRY(hipMemsetAsync(static_cast<unsigned char*>(O.d_parts.p) + key_bytes, 0, flag_bytes, O.stream));
+    if (O.d_parts.reserve(2 * (key_bytes + flag_bytes), O.stream) < 0) return -1;
+    BLURRILY_HIP_TRY(hipMemsetAsync(O.d_parts.p, 0, 2 * (key_bytes + flag_bytes), O.stream));
   }
-  const DeviceIndex& ix = m->dev;
-  FindArgs a{};
-  a.slice_se = ix.d_slice_se; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
-  a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
-  a.win_max_tri = ix.d_win_max_tri; a.nib_windows = ix.nib_windows; a.dense_min8 = ix.dense_min8;
-  a.limit = limit; a.keep = limit; a.pool_cap = 512;
-#ifdef BLURRILY_TRACE
-  if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
-  a.phase_clocks = m->d_phase;                         // (trace build: find_one_kernel's wall-clock marks, 16 per workgroup)
-#endif
-  // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond
-  uint32_t per = 1;
-  if (ix.n_windows > kOneMaxGrid) { per = (ix.n_windows + kOneMaxGrid - 1) / kOneMaxGrid; per += per & 1u; }
-  per = std::max(per, O.min_per);                         // (a test's way to the several-steps-per-workgroup path on a small image)
-  const uint32_t grid = (ix.n_windows + per - 1) / per;
-  unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p);
   const uint32_t seq = ++O.seq ? O.seq : ++O.seq;         // (never 0: what the words hold before the first find)
-  unsigned char* h_words = O.h_out + kOneMaxNeedles * kOneRowBytes;     // [needle][2]: rows, sequence word
-  unsigned char* d_words = O.d_out + kOneMaxNeedles * kOneRowBytes;
-  if (launch_find_one(a, codes, T, n_rows, per, grid, reinterpret_cast<unsigned long long*>(dp),
-                      reinterpret_cast<uint32_t*>(dp + key_bytes), reinterpret_cast<trigram_match_t*>(O.d_out),
-                      reinterpret_cast<uint32_t*>(d_words), seq, O.stream) < 0)
-    return -1;
+  // one launch per image: [0] the base image, [1] the delta image of the pending puts (its own lists, flags and rows)
+  auto launch_on = [&](const DeviceIndex& ix, const uint32_t* d_tomb, int which) -> int {
+    FindArgs a{};
+    a.slice_se = ix.d_slice_se; a.ent = ix.d_ent; a.ref_of_rank = ix.d_ref_of_rank;
+    a.weight_of_rank = ix.d_weight_of_rank; a.n_refs = ix.n_refs; a.n_windows = ix.n_windows;
+    a.win_max_tri = ix.d_win_max_tri; a.nib_windows = ix.nib_windows; a.dense_min8 = ix.dense_min8;
+    a.limit = limit; a.keep = limit; a.pool_cap = 512;
+    a.tomb = d_tomb;
+#ifdef BLURRILY_TRACE
+    if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
+    if (which == 0) a.phase_clocks = m->d_phase;       // (trace build: find_one_kernel's wall-clock marks, 16 per workgroup)
+#endif
+    // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond
+    uint32_t per = 1;
+    if (ix.n_windows > kOneMaxGrid) { per = (ix.n_windows + kOneMaxGrid - 1) / kOneMaxGrid; per += per & 1u; }
+    per = std::max(per, O.min_per);                       // (a test's way to the several-steps-per-workgroup path on a small image)
+    const uint32_t grid = (ix.n_windows + per - 1) / per;
+    unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p) + which * (key_bytes + flag_bytes);
+    unsigned char* d_rows = O.d_out + which * kOneHostBytes;
+    return launch_find_one(a, codes, T, n_rows, per, grid, reinterpret_cast<unsigned long long*>(dp),
+                           reinterpret_cast<uint32_t*>(dp + key_bytes), reinterpret_cast<trigram_match_t*>(d_rows),
+                           reinterpret_cast<uint32_t*>(d_rows + kOneMaxNeedles * kOneRowBytes), seq, O.stream);
+  };
+  if (launch_on(m->dev, with_tomb ? m->dev.d_tomb : nullptr, 0) < 0) return -1;
+  if (with_delta && launch_on(m->delta, nullptr, 1) < 0) return -1;
   // A row's last store is its sequence word; the host polls the words in the pinned page instead of waiting for the
   // runtime to notice the kernel's completion signal (an interrupt or a slower poll: 10 us and more).
-  volatile uint32_t* words = reinterpret_cast<volatile uint32_t*>(h_words);
   uint64_t spins = 0;
-  for (uint32_t r = 0; r < n_rows; ++r) {
-    while (words[2 * r + 1] != seq) {
+  for (int which = 0; which < (with_delta ? 2 : 1); ++which) {
+    volatile uint32_t* words = reinterpret_cast<volatile uint32_t*>(O.h_out + which * kOneHostBytes + kOneMaxNeedles * kOneRowBytes);
+    for (uint32_t r = 0; r < n_rows; ++r) {
+      while (words[2 * r + 1] != seq) {
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+        __builtin_ia32_pause();
 #endif
-      if ((++spins & 0xFFFFFu) == 0) {                    // every few milliseconds: is the stream still alive?
-        const hipError_t q = hipStreamQuery(O.stream);
-        if (q == hipSuccess && words[2 * r + 1] != seq) { std::fprintf(stderr, "blurrily_hip: find_one finished without its rows\n"); errno = EIO; return -1; }
-        if (q != hipSuccess && q != hipErrorNotReady) { std::fprintf(stderr, "blurrily_hip: find_one: %s\n", hipGetErrorString(q)); errno = EIO; return -1; }
+        if ((++spins & 0xFFFFFu) == 0) {                  // every few milliseconds: is the stream still alive?
+          const hipError_t q = hipStreamQuery(O.stream);
+          if (q == hipSuccess && words[2 * r + 1] != seq) { std::fprintf(stderr, "blurrily_hip: find_one finished without its rows\n"); errno = EIO; return -1; }
+          if (q != hipSuccess && q != hipErrorNotReady) { std::fprintf(stderr, "blurrily_hip: find_one: %s\n", hipGetErrorString(q)); errno = EIO; return -1; }
+        }
       }
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const volatile uint32_t* w0 = reinterpret_cast<const volatile uint32_t*>(O.h_out + kOneMaxNeedles * kOneRowBytes);
+  const volatile uint32_t* w1 = reinterpret_cast<const volatile uint32_t*>(O.h_out + kOneHostBytes + kOneMaxNeedles * kOneRowBytes);
   for (uint32_t r = 0; r < n_rows; ++r) {
-    const uint32_t got = words[2 * r], i = row_of[r];
-    counts[i] = got < limit ? got : uint32_t(limit);
-    std::memcpy(results + size_t(i) * limit, O.h_out + r * kOneRowBytes, size_t(counts[i]) * sizeof(trigram_match_t));
+    const uint32_t i = row_of[r];
+    const trigram_match_t* a_rows = reinterpret_cast<const trigram_match_t*>(O.h_out + r * kOneRowBytes);
+    const uint32_t got_a = w0[2 * r], na = got_a < limit ? got_a : uint32_t(limit);
+    trigram_match_t* out = results + size_t(i) * limit;
+    if (!with_delta) {
+      counts[i] = na;
+      std::memcpy(out, a_rows, size_t(na) * sizeof(trigram_match_t));
+      continue;
+    }
+    // result order: matches descending, weight ascending, reference ascending (storage.c:129-138, :566)
+    const trigram_match_t* b_rows = reinterpret_cast<const trigram_match_t*>(O.h_out + kOneHostBytes + r * kOneRowBytes);
+    const uint32_t got_b = w1[2 * r], nb_ = got_b < limit ? got_b : uint32_t(limit);
+    uint32_t ia = 0, ib = 0, k = 0;
+    while (k < limit && (ia < na || ib < nb_)) {
+      bool take_a;
+      if (ia >= na) take_a = false;
+      else if (ib >= nb_) take_a = true;
+      else {
+        const trigram_match_t x = a_rows[ia], y = b_rows[ib];
+        take_a = x.matches != y.matches ? x.matches > y.matches : x.weight != y.weight ? x.weight < y.weight : x.reference < y.reference;
+      }
+      out[k++] = take_a ? a_rows[ia++] : b_rows[ib++];
+    }
+    counts[i] = k;
   }
   O.taken += n_rows;
   return 0;

@@ -3471,7 +3471,6 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
   using S = ScanTraits<CT>;
   using P = Packing<CT>;
   constexpr bool kNib = std::is_same<CT, Nib>::value;
-  (void)A;
   constexpr uint32_t kNW = NT / 64, kR = S::kVecs / NT;      // rounds: a wave owns kR * 64 consecutive vectors
   static_assert(S::kVecs == 4096 && kNW * kR * 64 == 4096 && kNW <= 16, "the waves share the 4 096 vectors evenly");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -3489,6 +3488,34 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
     if (i < nvec) cnt128[i] = make_uint4(0, 0, 0, 0);
   }
   S::clear_unreached_pad(cnt128, nvec, tid);
+  if (A.tomb) {
+    // References deleted since the image was built (storage.c:584-612) must not take a place: their counters go to zero
+    // in the registers, before anything is counted.  Vector i holds the byte cells of in-window ranks 16 i .. 16 i + 15
+    // -- of BOTH windows of a pair with 4-bit counters (even window: low nibbles) --, byte 3 - (r & 3) of word (r >> 2) & 3:
+    // sixteen tombstone bits per window, aligned (a window starts at a multiple of sixteen ranks).
+    static_assert(kWindowRanks % 16 == 0, "a vector's tombstone bits sit in one half of one word");
+#pragma unroll
+    for (uint32_t j = 0; j < kR; ++j) {
+      const uint32_t i = (wid * kR + j) * 64 + lane;
+      if (i >= nvec) continue;
+      const uint32_t r0 = wbase + 16 * i, r1 = r0 + kWindowRanks;
+      const uint32_t dead0 = r0 < A.n_refs ? (A.tomb[r0 >> 5] >> (r0 & 31u)) & 0xFFFFu : 0u;
+      const uint32_t dead1 = kNib && r1 < A.n_refs ? (A.tomb[r1 >> 5] >> (r1 & 31u)) & 0xFFFFu : 0u;
+      if ((dead0 | dead1) == 0) continue;
+      uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t gone = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) {                 // rank 4 k + b of the vector: byte 3 - b of word k
+          if ((dead0 >> (4 * k + b)) & 1u) gone |= (kNib ? 0x0Fu : 0xFFu) << (8 * (3 - b));
+          if ((dead1 >> (4 * k + b)) & 1u) gone |= 0xF0u << (8 * (3 - b));
+        }
+        d[k] &= ~gone;
+      }
+      v[j] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  }
   // counters of this thread that reach `bound`
   auto reach = [&](const uint32_t bound) {
     const typename S::Need nq = S::prepare(bound);

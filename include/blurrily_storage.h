@@ -90,9 +90,10 @@ int blurrily_storage_delete(trigram_map haystack, uint32_t reference);
  * caller-allocated `results`, ordered by matches descending, weight ascending,
  * reference ascending.  Returns the row count, or -1 (errno ENODEV) when no
  * GPU is usable.  ONE kernel launch and no copy for a needle of at most 64
- * distinct trigrams at a limit of 1..120 on a map without mutations the device
- * image has not absorbed yet (option "one_launch"); otherwise one element of
- * blurrily_storage_find_batch. */
+ * distinct trigrams at a limit of 1..120 (option "one_launch"; a second launch
+ * over the delta image while puts are pending); otherwise one element of
+ * blurrily_storage_find_batch -- which takes the same launch for up to sixteen
+ * such needles, a row of the grid each. */
 int blurrily_storage_find(trigram_map haystack, const char* needle,
                           uint16_t limit, trigram_match results);
 

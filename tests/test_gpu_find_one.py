@@ -5,8 +5,10 @@ reference (oracle/_ref, where it travelled) or the oracle, and against the batch
   * thousands of IDENTICAL strings: a window whose counters tie by the thousand at the bound (storage.c:566's order:
     the lowest references win);
   * several windows per workgroup (option "one_windows_per_wg": the steps after the first arrive with a threshold);
-  * what must NOT take the launch: limits of 0 and above 120, needles of more than 64 distinct trigrams, maps with
-    pending puts or tombstones -- same rows, by the batch's way ("one_taken" tells which way a find went)."""
+  * mutations the device image has not absorbed: tombstones inside the select, pending puts by a second launch over
+    the delta image, merged on the host;
+  * what must NOT take the launch: limits of 0 and above 120, needles of more than 64 distinct trigrams, timing mode
+    -- same rows, by the batch's way ("one_taken" tells which way a find went)."""
 import os
 import tempfile
 
@@ -146,16 +148,61 @@ def test_what_goes_the_batchs_way_instead(geo):
     assert _find(m, nd, 0) == []                                            # limit 0: no rows (the C entry point takes it as it is)
     long_needle = b" ".join(hay_strings[k] for k in range(20, 40))[:250]    # more than 64 distinct trigrams
     assert len(set(Oracle.tokenise(long_needle))) > 64 and goes_one(long_needle, 10) == 0
-    # a pending put: base + delta images, merged -- the batch's way until the log folds into a rebuilt base
-    assert m.put(b"zanzibar city", 40_001, 0) > 0 and o.put(b"zanzibar city", 40_001, 0) > 0
-    assert goes_one(b"zanzibar city", 10) == 0 and goes_one(nd, 10) == 0
-    # a tombstone
-    assert m.delete(12) == o.delete(12)
-    assert goes_one(nd, 10) == 0
-    # timing mode describes the batch's launches: not taken either
+    # timing mode describes the batch's launches: not taken
     m.set_timing(True)
     assert goes_one(nd, 10) == 0
     m.set_timing(False)
+
+
+def test_mutations_the_image_has_not_absorbed(geo):
+    """Deletes since the base image was built are tombstone bits the select looks at (a deleted reference takes no place:
+    storage.c:584-612), puts since then live in the delta image, searched by a second launch and merged on the host
+    (storage.c:398-473) -- the single find stays ONE launch per image, and says what the reference says."""
+    m0, chk, strings = geo
+    hay_strings = strings[:150_000]                            # three windows, full of twins
+    packed, off = _pack(hay_strings)
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(packed, off, np.arange(1, 150_001, dtype=np.uint32))
+    o.put_many(packed, off)
+    rng = np.random.default_rng(12)
+    needles = [hay_strings[int(k)] for k in rng.integers(0, 150_000, size=60)]
+    needles += [nd[:-1] for nd in needles[:20]] + [b" ".join(hay_strings[k] for k in range(300, 303))[:60]]   # (the last: over 15 trigrams)
+    for nd in needles[:5]:
+        assert _find(m, nd, 10) == o.find(nd, 10)              # builds the base image
+    # delete the best matches of the needles (what a find would return first), and a spread of others
+    victims = set()
+    for nd in needles:
+        for row in o.find(nd, 3):
+            victims.add(row[0])
+    victims |= set(range(7, 150_000, 997))
+    for ref in sorted(victims):
+        assert m.delete(ref) == o.delete(ref)
+    # new strings: twins of haystack strings (ties with base references) and fresh ones
+    for k, i in enumerate(rng.integers(0, 150_000, size=200)):
+        s_new = hay_strings[int(i)] if k % 2 else hay_strings[int(i)] + b" nova"
+        assert m.put(s_new, 200_000 + k, 0) == o.put(s_new, 200_000 + k, 0)
+    info = m.device_info()
+    taken = m.get_option("one_taken")
+    for limit in (1, 10, 64, 120):
+        for nd in needles:
+            assert _find(m, nd, limit) == o.find(nd, limit), (nd, limit)
+    assert m.get_option("one_taken") - taken == 4 * len(needles)            # every one of them one launch per image
+    info = m.device_info()
+    assert info["base_builds"] == 1 and info["n_tombstones"] > 0 and info["n_pending"] == 200
+    # a handful at a time, and several windows per workgroup
+    m.set_option("one_windows_per_wg", 2)
+    pk, po = _pack(needles[:16])
+    rows, counts = m.find_batch_packed(pk, po, 10)
+    for i, nd in enumerate(needles[:16]):
+        assert rows[i, :counts[i]].tolist() == o.find(nd, 10), nd
+    m.set_option("one_windows_per_wg", 0)
+    # delete a pending put, put a deleted reference back: the log keeps up
+    assert m.delete(200_001) == o.delete(200_001)
+    back = sorted(victims)[0]
+    assert m.put(b"zanzibar city", back, 0) == o.put(b"zanzibar city", back, 0)
+    for nd in needles[:30] + [b"zanzibar city"]:
+        assert _find(m, nd, 10) == o.find(nd, 10), nd
+    m.close()
 
 
 def test_a_handful_of_needles_share_one_launch(geo):
