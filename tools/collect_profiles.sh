@@ -8,7 +8,7 @@
 #   pmc_{fetch,write,tcc}_<workload>/  rocprofv3 --pmc passes, one counter group per run, per workload
 #   traffic.json                       tools/traffic_summary.py over those passes
 # (PROFILE_COMMIT=<short hash> in the environment stamps traffic.json: the GPU box has no .git)
-tag=${1:-r04}
+tag=${1:-r05}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -19,6 +19,7 @@ python $root/bench.py > $out/bench.json 2> $out/bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra --latency-probes 0 > $out/stats_bench.json 2> $out/stats_bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline --latency-probes 0 > $out/stats_skewed.json 2> $out/stats_skewed.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x4 -o bench -- python $root/bench.py --workload geonames_x4 --no-cpu-baseline --latency-probes 0 > $out/stats_x4.json 2> $out/stats_x4.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_words -o bench -- python $root/bench.py --workload words --no-cpu-baseline --latency-probes 0 > $out/stats_words.json 2> $out/stats_words.log
 # the sweep the bench run above took for a workload (its measured choice): the PMC passes force the same one
 sweep_of() { python - "$out/bench.json" "$1" <<'PY'
 import json, sys

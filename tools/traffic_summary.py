@@ -16,7 +16,8 @@ import os
 import sqlite3
 import sys
 
-OURS = ("find_kernel", "wsweep_kernel", "tokenise", "finalize_rows", "merge_", "normalise", "apply_tombstones")
+OURS = ("find_kernel", "find_small_kernel", "find_one_kernel", "wsweep_kernel", "tokenise", "finalize_rows", "merge_", "normalise",
+        "apply_tombstones")
 CALLS_PER_RUN = 1
 
 
