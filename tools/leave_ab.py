@@ -34,7 +34,10 @@ for _ in range(4):
     rows, counts = m.find_batch_packed(q, qo, limit)
     ms.append(m.device_info()["last_find_kernel_ms"])
 tag = os.path.basename(os.environ.get("BLURRILY_LIB", "current"))
-out = f"{tag} sweep {m.get_option('last_sweep')} kernel ms " + " ".join(f"{x:.1f}" for x in ms) + f"  min {min(ms):.1f}"
+import zlib
+live_ = np.arange(limit)[None, :] < counts[:, None].astype(np.int64)
+crc = zlib.crc32(np.ascontiguousarray(np.where(live_[:, :, None], rows, 0)).tobytes()) ^ zlib.crc32(counts.tobytes())
+out = f"{tag} crc {crc:08x} sweep {m.get_option('last_sweep')} kernel ms " + " ".join(f"{x:.1f}" for x in ms) + f"  min {min(ms):.1f}"
 if os.environ.get("AB_CHECK"):
     m.set_option("nm_min_windows", 1 << 20)
     rows1, counts1 = m.find_batch_packed(q, qo, limit)
