@@ -3697,6 +3697,114 @@ struct OneArgs {
   uint32_t seq;
 };
 
+// find_one_kernel's last workgroup: the best `keep` of the G lists of `keep` slots (its own, the last, still in its pool)
+// into `pool` (the head of s_counters), unsorted.
+// A list is sorted, a key is level << 32 | rank with level = T - matches, and list g's windows lie in front of list
+// g + 1's: LOWER ranks.  The union's order is therefore: by level, inside a level by list, inside a list by place -- and
+// its best `keep` are every key of a level below L, the first level at which the levels' sizes add up to `keep`, plus
+// the first keep - (keys below L) keys of level L in list order.  Nothing is sorted to find them:
+//   * every slot's LEVEL goes to LDS as a byte (the lists' padding, kKeyInf, counts as one more level): all of a
+//     thread's loads of a round in flight at once, one global round trip per 8 192 slots;
+//   * the levels' sizes come from the places where a list CHANGES level -- a run of level l from place s to place e adds
+//     e - s to the level: + e where the next run starts (or the list ends), - s where it starts; two atomics per run, a
+//     handful per list, whatever the limit;
+//   * level L's runs leave their first and last place per list; a prefix sum over the lists tells every key of the
+//     level how many of its level lie in front of it.
+// Exactly min(keep, keys there are) keys pass -- read again from where they lie, a few loads --, and compact_pool's rank
+// count puts those few in order.
+// (Through round 5's first version: the keys not above the keep-th smallest list head, and of those the ones at place p
+// of a list with r smaller heads in front where r + p < keep -- up to keep (keep + 1) / 2 keys, sorted by compact_pool's
+// bitonic network: 32 us at Geonames scale and limit 100, 64 us on a haystack of massive ties, of a find's 70 and 104.
+// Before that, one wave advancing one list per round: a dependent load from memory per row.  And a version of THIS
+// merge with a thread's slots in registers, an unrolled loop over the 30 of the largest grid times the largest limit
+// with a uniform skip per unused slot: every jump was an instruction-cache miss, 3 us at limit 10.)
+template <int NT>
+__device__ __forceinline__ void one_merge(const FindArgs& A, const unsigned long long* part_keys, uint32_t* s_counters,
+                                          const unsigned long long* s_pool, Control* ctl, const uint32_t nres,
+                                          const uint32_t keep, const uint32_t g, const uint32_t G) {
+  constexpr uint32_t kPadLevel = 64;                                   // (a needle's levels: 0 .. T - 1 <= 63)
+  constexpr uint32_t kRound = 8;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  uint32_t* const w32 = s_counters;                                    // (the counters are done with)
+  unsigned long long* const pool = reinterpret_cast<unsigned long long*>(w32);   // [kOnePool]
+  uint32_t* const hist = w32 + 2 * kOnePool;                           // [128] keys per level
+  uint32_t* const startL = hist + 128;                                 // [kOneMaxGrid] level L's first place in a list ...
+  uint32_t* const endL = startL + kOneMaxGrid;                         //   ... the place behind its last ...
+  uint32_t* const before = endL + kOneMaxGrid;                         //   ... level-L keys in the lists in front
+  unsigned char* const lvl = reinterpret_cast<unsigned char*>(before + kOneMaxGrid);   // [G * keep] a slot's level
+  static_assert((2 * kOnePool + 128 + 3 * kOneMaxGrid) * 4 + kOneMaxGrid * kOneMaxKeep <= kWindowSize && kOnePool >= kOneMaxKeep,
+                "merge scratch");
+  const uint32_t own0 = g * keep, total = G * keep;                    // (this workgroup's own list -- the last -- comes from its pool)
+  for (uint32_t i = tid; i < 128 + 3 * kOneMaxGrid; i += NT) hist[i] = 0;
+  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; }
+  auto slot = [&](const uint32_t idx) -> unsigned long long {
+    if (idx < own0) return __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return idx - own0 < nres ? s_pool[idx - own0] : kKeyInf;
+  };
+#pragma unroll 1
+  for (uint32_t base = tid; base < total; base += kRound * NT) {       // (base - tid: uniform)
+    unsigned long long k[kRound];
+#pragma unroll
+    for (uint32_t j = 0; j < kRound; ++j) {
+      const uint32_t idx = base + j * NT;
+      k[j] = kKeyInf;
+      if (idx < total) k[j] = slot(idx);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kRound; ++j) {
+      const uint32_t idx = base + j * NT;
+      if (idx < total) lvl[idx] = static_cast<unsigned char>(min(uint32_t(k[j] >> 32), kPadLevel));
+    }
+  }
+  __syncthreads();                                       // the scratch is zeroed, the levels are there
+  ONE_MARK(A, 10);
+  // idx / keep for idx < 2^16 by one multiplication (exact: idx (magic - 2^32 / keep) < 2^32 / keep)
+  const uint32_t magic = keep > 1 ? 0xFFFFFFFFu / keep + 1u : 0u;
+#pragma unroll 2
+  for (uint32_t idx = tid; idx < total; idx += NT) {
+    const uint32_t list = keep > 1 ? __umulhi(idx, magic) : idx, p = idx - list * keep;
+    const uint32_t l = lvl[idx], lp = p ? lvl[idx - 1] : kPadLevel;
+    if (p != 0 && lp != l) { atomicAdd(&hist[lp], p); atomicSub(&hist[l], p); }
+    if (p == keep - 1 && l != kPadLevel) atomicAdd(&hist[l], keep);
+  }
+  __syncthreads();
+  // every wave for itself: lane l holds level l's size
+  const uint32_t h_l = hist[lane], h_incl = wave_inclusive_sum(h_l);
+  const unsigned long long reached = __ballot(h_incl >= keep);
+  const uint32_t L = reached ? uint32_t(__builtin_ctzll(reached)) : kPadLevel;      // (kPadLevel: fewer than keep keys in all, every one passes)
+  const uint32_t quota = L < kPadLevel ? keep - (__builtin_amdgcn_readlane(h_incl, L) - __builtin_amdgcn_readlane(h_l, L)) : 0u;
+  if (L < kPadLevel) {
+#pragma unroll 2
+    for (uint32_t idx = tid; idx < total; idx += NT) {
+      const uint32_t list = keep > 1 ? __umulhi(idx, magic) : idx, p = idx - list * keep;
+      const uint32_t l = lvl[idx], lp = p ? lvl[idx - 1] : kPadLevel;
+      if (l == L && (p == 0 || lp != L)) startL[list] = p;
+      if (p != 0 && lp == L && l != L) endL[list] = p;
+      if (p == keep - 1 && l == L) endL[list] = keep;
+    }
+    __syncthreads();
+    if (tid < 64) {                                      // lane t: lists 4 t .. 4 t + 3
+      uint32_t c[4], sum = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) { const uint32_t li = 4 * tid + i; c[i] = li < G ? endL[li] - startL[li] : 0u; sum += c[i]; }
+      uint32_t run = wave_inclusive_sum(sum) - sum;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) { before[4 * tid + i] = run; run += c[i]; }
+    }
+    __syncthreads();
+  }
+  ONE_MARK(A, 11);
+#pragma unroll 2
+  for (uint32_t idx = tid; idx < total; idx += NT) {
+    const uint32_t l = lvl[idx];
+    if (l > L || l == kPadLevel) continue;
+    const uint32_t list = keep > 1 ? __umulhi(idx, magic) : idx, p = idx - list * keep;
+    if (l == L && before[list] + (p - startL[list]) >= quota) continue;
+    pool[atomicAdd(&ctl->pool_n, 1u)] = slot(idx);       // (at most keep keys)
+  }
+  __syncthreads();
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const OneArgs O) {
   __shared__ __attribute__((aligned(16))) uint32_t s_counters[kWindowSize / 4];
@@ -3764,73 +3872,9 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
     } while (pending);
   }
   ONE_MARK(A, 9);
-  // The merge.  The answer lies among the keys that are not above H, the keep-th smallest of the lists' HEADS (keep
-  // heads are keep keys), and a key at place p of a list whose head has r smaller heads in front of it has r + p
-  // smaller keys in front of it: it passes only with r + p < keep.  At most keep (keep + 1) / 2 keys pass -- usually a
-  // few more than keep -- and compact_pool sorts those.  Every thread loads the lists' heads and its share of the
-  // first 8 192 slots AT ONCE (one global round trip; more slots -- a large grid times a large limit -- follow in
-  // further rounds).  (Through its first version the last workgroup merged like merge_parts_small_kernel, one wave
-  // advancing one list per round: every round a dependent load of a key another XCD had written, i.e. from memory --
-  // 2 us a row, 20 us at limit 10.)
-  constexpr uint32_t kPerThread = 8;
-  unsigned long long* const heads = s_pool;                            // [G]
-  uint32_t* const head_rank = reinterpret_cast<uint32_t*>(s_pool + kOneMaxGrid);   // [G] heads smaller than a list's
-  unsigned long long* const pool = reinterpret_cast<unsigned long long*>(s_counters);   // (the counters are done with)
-  constexpr uint32_t kMergeCap = kWindowSize / 8;                      // 8192 keys
-  static_assert(kMergeCap >= kOneMaxKeep * (kOneMaxKeep + 1) / 2 && kOnePool >= kOneMaxGrid + kOneMaxGrid / 2, "merge pool / heads");
-  const uint32_t own0 = g * keep;                                      // (this workgroup's own list -- the last -- comes from its pool)
-  unsigned long long mine[kPerThread];
-#pragma unroll
-  for (uint32_t j = 0; j < kPerThread; ++j) {
-    const uint32_t idx = tid + j * NT;
-    mine[j] = kKeyInf;
-    if (idx < own0) mine[j] = __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  unsigned long long head = kKeyInf;
-  if (tid < g) head = __hip_atomic_load(&part_keys[size_t(tid) * keep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long own_key = kKeyInf;
-  if (tid < nres) own_key = s_pool[tid];                  // (before s_pool becomes the heads' array)
-  __syncthreads();
-  if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; ctl->floor = kKeyInf; heads[g] = own_key; }
-  if (tid < g) heads[tid] = head;
-  __syncthreads();
-  ONE_MARK(A, 10);
-  if (tid < G) {                                         // H: the head with exactly keep - 1 heads below it (keys are distinct)
-    const unsigned long long h = heads[tid];
-    uint32_t below = 0;
-    const uint32_t G2 = G & ~1u;
-    for (uint32_t i = 0; i < G2; i += 2) {               // (two heads per read, the same address in every lane)
-      const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(heads + i);
-      below += uint32_t(two.x < h) + uint32_t(two.y < h);
-    }
-    if (G2 < G) below += heads[G2] < h ? 1u : 0u;
-    head_rank[tid] = h == kKeyInf ? keep : below;
-    if (h != kKeyInf && below == keep - 1) ctl->floor = h;
-  }
-  __syncthreads();
-  const unsigned long long H = ctl->floor;
-  auto pass = [&](const unsigned long long key, const uint32_t idx) {
-    if (key == kKeyInf || key > H) return;
-    const uint32_t list = idx / keep, p = idx - list * keep;
-    if (head_rank[list] + p >= keep) return;
-    const uint32_t at = atomicAdd(&ctl->pool_n, 1u);
-    if (at < kMergeCap) pool[at] = key;                  // (never full: see the bound above)
-  };
-#pragma unroll
-  for (uint32_t j = 0; j < kPerThread; ++j) pass(mine[j], tid + j * NT);
-  for (uint32_t base = kPerThread * NT; base < own0; base += kPerThread * NT) {   // (beyond 8 192 slots: further rounds)
-#pragma unroll
-    for (uint32_t j = 0; j < kPerThread; ++j) {
-      const uint32_t idx = base + tid + j * NT;
-      mine[j] = idx < own0 ? __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kKeyInf;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < kPerThread; ++j) pass(mine[j], base + tid + j * NT);
-  }
-  pass(own_key, own0 + tid);
-  __syncthreads();
-  ONE_MARK(A, 11);
-  compact_pool<NT>(pool, ctl, kMergeCap, keep);
+  one_merge<NT>(A, part_keys, s_counters, s_pool, ctl, nres, keep, g, G);
+  unsigned long long* const pool = reinterpret_cast<unsigned long long*>(s_counters);
+  compact_pool<NT>(pool, ctl, kOnePool, keep);
   ONE_MARK(A, 12);
   const uint32_t n_out = ctl->pool_n;
   if (tid < n_out) {
