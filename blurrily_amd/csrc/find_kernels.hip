@@ -3702,40 +3702,40 @@ struct OneArgs {
 // A list is sorted, a key is level << 32 | rank with level = T - matches, and list g's windows lie in front of list
 // g + 1's: LOWER ranks.  The union's order is therefore: by level, inside a level by list, inside a list by place -- and
 // its best `keep` are every key of a level below L, the first level at which the levels' sizes add up to `keep`, plus
-// the first keep - (keys below L) keys of level L in list order.  Nothing is sorted to find them:
+// the first keep - (keys below L) keys of level L in list order: of every list a PREFIX.  Nothing is sorted to find them:
 //   * every slot's LEVEL goes to LDS as a byte (the lists' padding, kKeyInf, counts as one more level): all of a
 //     thread's loads of a round in flight at once, one global round trip per 8 192 slots;
-//   * the levels' sizes come from the places where a list CHANGES level -- a run of level l from place s to place e adds
-//     e - s to the level: + e where the next run starts (or the list ends), - s where it starts; two atomics per run, a
-//     handful per list, whatever the limit;
-//   * level L's runs leave their first and last place per list; a prefix sum over the lists tells every key of the
-//     level how many of its level lie in front of it.
-// Exactly min(keep, keys there are) keys pass -- read again from where they lie, a few loads --, and compact_pool's rank
-// count puts those few in order.
+//   * for every (list, level l = 1 .. T) the place where the list's levels reach l -- a binary search over the list's
+//     bytes, a wave per level, a lane per list; their sum over the lists is the number of keys BELOW level l, which
+//     gives L, and the places themselves say where a list's keys of level L start and end: work per (list, level),
+//     not per slot (a walk over the slots, however lean, costs the VALU 12 900 x 25 instructions at Geonames scale and
+//     limit 100: 2 us a pass);
+//   * one wave's prefix sums over the lists turn the places into the length of every list's passing prefix and its
+//     offset in the output; output slot i finds its (list, place) by a binary search over the offsets and loads that key.
+// Exactly min(keep, keys there are) keys arrive; compact_pool's rank count puts those few in order.
 // (Through round 5's first version: the keys not above the keep-th smallest list head, and of those the ones at place p
 // of a list with r smaller heads in front where r + p < keep -- up to keep (keep + 1) / 2 keys, sorted by compact_pool's
 // bitonic network: 32 us at Geonames scale and limit 100, 64 us on a haystack of massive ties, of a find's 70 and 104.
 // Before that, one wave advancing one list per round: a dependent load from memory per row.  And a version of THIS
 // merge with a thread's slots in registers, an unrolled loop over the 30 of the largest grid times the largest limit
-// with a uniform skip per unused slot: every jump was an instruction-cache miss, 3 us at limit 10.)
+// with a uniform skip per unused slot: every jump was an instruction-cache miss, 3 us at limit 10 -- this code runs
+// once per launch, cold: its loops are rolled.)
 template <int NT>
 __device__ __forceinline__ void one_merge(const FindArgs& A, const unsigned long long* part_keys, uint32_t* s_counters,
                                           const unsigned long long* s_pool, Control* ctl, const uint32_t nres,
-                                          const uint32_t keep, const uint32_t g, const uint32_t G) {
+                                          const uint32_t T, const uint32_t keep, const uint32_t g, const uint32_t G) {
   constexpr uint32_t kPadLevel = 64;                                   // (a needle's levels: 0 .. T - 1 <= 63)
-  constexpr uint32_t kRound = 8;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  constexpr uint32_t kRound = 8, kNW = NT / 64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t* const w32 = s_counters;                                    // (the counters are done with)
   unsigned long long* const pool = reinterpret_cast<unsigned long long*>(w32);   // [kOnePool]
-  uint32_t* const hist = w32 + 2 * kOnePool;                           // [128] keys per level
-  uint32_t* const startL = hist + 128;                                 // [kOneMaxGrid] level L's first place in a list ...
-  uint32_t* const endL = startL + kOneMaxGrid;                         //   ... the place behind its last ...
-  uint32_t* const before = endL + kOneMaxGrid;                         //   ... level-L keys in the lists in front
-  unsigned char* const lvl = reinterpret_cast<unsigned char*>(before + kOneMaxGrid);   // [G * keep] a slot's level
-  static_assert((2 * kOnePool + 128 + 3 * kOneMaxGrid) * 4 + kOneMaxGrid * kOneMaxKeep <= kWindowSize && kOnePool >= kOneMaxKeep,
-                "merge scratch");
+  uint32_t* const below = w32 + 2 * kOnePool;                          // [128] keys of a level below l, l = 1 .. T
+  uint32_t* const off = below + 128;                                   // [kOneMaxGrid] where a list's passing prefix starts in the output
+  unsigned char* const reach = reinterpret_cast<unsigned char*>(off + kOneMaxGrid);   // [65][kOneMaxGrid] the place where a list's levels reach l
+  unsigned char* const lvl = reach + 65 * kOneMaxGrid;                 // [G * keep] a slot's level
+  static_assert((2 * kOnePool + 128 + kOneMaxGrid) * 4 + 65 * kOneMaxGrid + kOneMaxGrid * kOneMaxKeep <= kWindowSize &&
+                kOnePool >= kOneMaxKeep && kOneMaxKeep < 256, "merge scratch");
   const uint32_t own0 = g * keep, total = G * keep;                    // (this workgroup's own list -- the last -- comes from its pool)
-  for (uint32_t i = tid; i < 128 + 3 * kOneMaxGrid; i += NT) hist[i] = 0;
   if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; }
   auto slot = [&](const uint32_t idx) -> unsigned long long {
     if (idx < own0) return __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3756,51 +3756,69 @@ __device__ __forceinline__ void one_merge(const FindArgs& A, const unsigned long
       if (idx < total) lvl[idx] = static_cast<unsigned char>(min(uint32_t(k[j] >> 32), kPadLevel));
     }
   }
-  __syncthreads();                                       // the scratch is zeroed, the levels are there
+  __syncthreads();                                       // the levels are there
   ONE_MARK(A, 10);
-  // idx / keep for idx < 2^16 by one multiplication (exact: idx (magic - 2^32 / keep) < 2^32 / keep)
-  const uint32_t magic = keep > 1 ? 0xFFFFFFFFu / keep + 1u : 0u;
-#pragma unroll 2
-  for (uint32_t idx = tid; idx < total; idx += NT) {
-    const uint32_t list = keep > 1 ? __umulhi(idx, magic) : idx, p = idx - list * keep;
-    const uint32_t l = lvl[idx], lp = p ? lvl[idx - 1] : kPadLevel;
-    if (p != 0 && lp != l) { atomicAdd(&hist[lp], p); atomicSub(&hist[l], p); }
-    if (p == keep - 1 && l != kPadLevel) atomicAdd(&hist[l], keep);
+#pragma unroll 1
+  for (uint32_t l = 1 + wv; l <= T; l += kNW) {          // a wave per level (uniform), a lane per list
+    uint32_t sum = 0;
+#pragma unroll 1
+    for (uint32_t g0 = 0; g0 < G; g0 += 64) {
+      const uint32_t li = g0 + lane;
+      uint32_t lo = 0;
+      if (li < G) {
+        const unsigned char* const row = lvl + li * keep;
+        uint32_t n = keep;
+        while (n) {                                      // the first place whose level is not below l
+          const uint32_t half = n >> 1;
+          if (row[lo + half] < l) { lo += half + 1; n -= half + 1; } else { n = half; }
+        }
+        reach[l * kOneMaxGrid + li] = static_cast<unsigned char>(lo);
+      }
+      sum += lo;
+    }
+    sum = wave_inclusive_sum(sum);
+    if (lane == 63) below[l] = sum;                      // (this wave's alone)
   }
   __syncthreads();
-  // every wave for itself: lane l holds level l's size
-  const uint32_t h_l = hist[lane], h_incl = wave_inclusive_sum(h_l);
-  const unsigned long long reached = __ballot(h_incl >= keep);
+  // every wave for itself: lane j holds the keys of levels up to j
+  const uint32_t upto = lane < T ? below[lane + 1] : 0u;
+  const unsigned long long reached = __ballot(lane < T && upto >= keep);
   const uint32_t L = reached ? uint32_t(__builtin_ctzll(reached)) : kPadLevel;      // (kPadLevel: fewer than keep keys in all, every one passes)
-  const uint32_t quota = L < kPadLevel ? keep - (__builtin_amdgcn_readlane(h_incl, L) - __builtin_amdgcn_readlane(h_l, L)) : 0u;
-  if (L < kPadLevel) {
-#pragma unroll 2
-    for (uint32_t idx = tid; idx < total; idx += NT) {
-      const uint32_t list = keep > 1 ? __umulhi(idx, magic) : idx, p = idx - list * keep;
-      const uint32_t l = lvl[idx], lp = p ? lvl[idx - 1] : kPadLevel;
-      if (l == L && (p == 0 || lp != L)) startL[list] = p;
-      if (p != 0 && lp == L && l != L) endL[list] = p;
-      if (p == keep - 1 && l == L) endL[list] = keep;
-    }
-    __syncthreads();
-    if (tid < 64) {                                      // lane t: lists 4 t .. 4 t + 3
-      uint32_t c[4], sum = 0;
-#pragma unroll
-      for (uint32_t i = 0; i < 4; ++i) { const uint32_t li = 4 * tid + i; c[i] = li < G ? endL[li] - startL[li] : 0u; sum += c[i]; }
-      uint32_t run = wave_inclusive_sum(sum) - sum;
-#pragma unroll
-      for (uint32_t i = 0; i < 4; ++i) { before[4 * tid + i] = run; run += c[i]; }
-    }
-    __syncthreads();
-  }
+  const uint32_t quota = L < kPadLevel ? keep - (L ? __builtin_amdgcn_readlane(upto, L - 1) : 0u) : 0u;
   ONE_MARK(A, 11);
-#pragma unroll 2
-  for (uint32_t idx = tid; idx < total; idx += NT) {
-    const uint32_t l = lvl[idx];
-    if (l > L || l == kPadLevel) continue;
-    const uint32_t list = keep > 1 ? __umulhi(idx, magic) : idx, p = idx - list * keep;
-    if (l == L && before[list] + (p - startL[list]) >= quota) continue;
-    pool[atomicAdd(&ctl->pool_n, 1u)] = slot(idx);       // (at most keep keys)
+  if (tid < 64) {                                        // lane t: lists 4 t .. 4 t + 3
+    uint32_t at[4], cnt[4], sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t li = 4 * tid + i;
+      at[i] = 0; cnt[i] = 0;
+      if (li < G) {
+        at[i] = L == kPadLevel ? reach[T * kOneMaxGrid + li] : (L ? reach[L * kOneMaxGrid + li] : 0u);
+        if (L != kPadLevel) cnt[i] = reach[(L + 1) * kOneMaxGrid + li] - at[i];
+      }
+      sum += cnt[i];
+    }
+    uint32_t in_front = wave_inclusive_sum(sum) - sum;   // keys of level L in the lists in front
+    sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {                   // a list's passing prefix: its keys below L, and of level L what the quota still wants
+      at[i] += min(cnt[i], quota > in_front ? quota - in_front : 0u);
+      in_front += cnt[i];
+      sum += at[i];
+    }
+    uint32_t o = wave_inclusive_sum(sum) - sum;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) { off[4 * tid + i] = o; o += at[i]; }
+    if (tid == 63) ctl->pool_n = o;
+  }
+  __syncthreads();
+  const uint32_t n_out = ctl->pool_n;
+  if (tid < n_out) {                                     // the list whose prefix holds output slot tid: the last with off <= tid
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = kOneMaxGrid / 2; step; step >>= 1)
+      if (off[lo + step] <= tid) lo += step;
+    pool[tid] = slot(lo * keep + (tid - off[lo]));
   }
   __syncthreads();
 }
@@ -3872,7 +3890,7 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
     } while (pending);
   }
   ONE_MARK(A, 9);
-  one_merge<NT>(A, part_keys, s_counters, s_pool, ctl, nres, keep, g, G);
+  one_merge<NT>(A, part_keys, s_counters, s_pool, ctl, nres, T, keep, g, G);
   unsigned long long* const pool = reinterpret_cast<unsigned long long*>(s_counters);
   compact_pool<NT>(pool, ctl, kOnePool, keep);
   ONE_MARK(A, 12);
