@@ -3420,6 +3420,29 @@ constexpr uint32_t kOnePool = 512;
 constexpr int      kOneThreads = 1024;                   // (512 -- eight waves, 256 VGPRs each -- measured: 35.4 against 33.5 us)
 constexpr uint32_t kOneAhead = 4;                        // units a wave loads before it counts the first of them
 
+// find_one_kernel's third counter layout: ONE window in 4-bit counters, 32 KiB -- wsweep_kernel's (ws_bump_pair_nib: word
+// (r >> 2) & 0x1FFF, nibble (r & 3) | (r >> 15) << 2: the low nibbles of a word hold ranks 4 w .. 4 w + 3 of the window's
+// lower half, the high ones ranks 32768 + 4 w ..).  A workgroup that owns a single window (every workgroup up to 256
+// windows) then reads and selects over 2 048 vectors instead of the pair layout's 4 096, half of whose nibbles it would
+// never touch: the select is VALU work per word (bisection 4.5 us, ties 4 us of a find's 31 at Geonames scale).
+struct Nib1 {};
+template <> struct Packing<Nib1> : Packing<Nib> {};
+template <> struct ScanTraits<Nib1> : ScanTraits<Nib> {
+  static constexpr uint32_t kVecs = kWsCntWords / 4;                // 2 048
+  static constexpr uint32_t kHalf = 32768;
+  // vector i holds ranks 16 i .. 16 i + 15 of the lower half and kHalf + 16 i .. of the upper half
+  static __device__ __forceinline__ uint32_t nvec(uint32_t wlen) { return (min(wlen, kHalf) + 15) / 16; }
+  // counter index = 8 * word + nibble
+  static __device__ __forceinline__ uint32_t rank_of(uint32_t wbase, uint32_t idx) {
+    return wbase + ((idx >> 3) << 2) + (idx & 3u) + ((idx >> 2) & 1u) * kHalf;
+  }
+  // slot 0xFFFF -- the padding -- is the top nibble of the last word: cleared here where the scan does not reach it,
+  // masked by the select where it does (a full window)
+  static __device__ __forceinline__ void clear_unreached_pad(uint4* cnt128, uint32_t nv, uint32_t tid) {
+    if (nv < kVecs && tid == 0) reinterpret_cast<uint32_t*>(cnt128)[kVecs * 4 - 1] = 0;
+  }
+};
+
 // this wave's units of one step: lane t holds trigram t's slice of the step's (even) window (a0, b0) and, with 4-bit
 // counters, of the odd one (a1, b1); unit k of the step belongs to wave k mod 16
 template <typename CT, int NT>
@@ -3452,7 +3475,10 @@ __device__ __forceinline__ void one_count(const uint16_t* __restrict__ ent, uint
       }
     }
 #pragma unroll
-    for (uint32_t i = 0; i < kOneAhead; ++i) bump_unit<CT>(cnt32, v[i], half[i]);
+    for (uint32_t i = 0; i < kOneAhead; ++i) {
+      if constexpr (std::is_same<CT, Nib1>::value) ws_bump8<false>(cnt32, v[i], 0u);
+      else bump_unit<CT>(cnt32, v[i], half[i]);
+    }
   }
 }
 
@@ -3470,9 +3496,10 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
                                            const uint32_t wlen) {
   using S = ScanTraits<CT>;
   using P = Packing<CT>;
-  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  constexpr bool kNib1 = std::is_same<CT, Nib1>::value;             // one window, 4-bit: lower half in a word's low nibbles
+  constexpr bool kNib = std::is_same<CT, Nib>::value || kNib1;       // two rank ranges per word (a pair's windows / a window's halves)
   constexpr uint32_t kNW = NT / 64, kR = S::kVecs / NT;      // rounds: a wave owns kR * 64 consecutive vectors
-  static_assert(S::kVecs == 4096 && kNW * kR * 64 == 4096 && kNW <= 16, "the waves share the 4 096 vectors evenly");
+  static_assert(kNW * kR * 64 == S::kVecs && kR >= 1 && kNW <= 16, "the waves share the vectors evenly");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t nvec = S::nvec(wlen);
   uint4 v[kR];
@@ -3488,6 +3515,11 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
     if (i < nvec) cnt128[i] = make_uint4(0, 0, 0, 0);
   }
   S::clear_unreached_pad(cnt128, nvec, tid);
+  if (kNib1) {                                           // (the padding's nibble, where the scan reaches it)
+#pragma unroll
+    for (uint32_t j = 0; j < kR; ++j)
+      if ((wid * kR + j) * 64 + lane == S::kVecs - 1) v[j].w &= 0x0FFFFFFFu;
+  }
   if (A.tomb) {
     // References deleted since the image was built (storage.c:584-612) must not take a place: their counters go to zero
     // in the registers, before anything is counted.  Vector i holds the byte cells of in-window ranks 16 i .. 16 i + 15
@@ -3498,7 +3530,7 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
     for (uint32_t j = 0; j < kR; ++j) {
       const uint32_t i = (wid * kR + j) * 64 + lane;
       if (i >= nvec) continue;
-      const uint32_t r0 = wbase + 16 * i, r1 = r0 + kWindowRanks;
+      const uint32_t r0 = wbase + 16 * i, r1 = r0 + (kNib1 ? 32768u : kWindowRanks);
       const uint32_t dead0 = r0 < A.n_refs ? (A.tomb[r0 >> 5] >> (r0 & 31u)) & 0xFFFFu : 0u;
       const uint32_t dead1 = kNib && r1 < A.n_refs ? (A.tomb[r1 >> 5] >> (r1 & 31u)) & 0xFFFFu : 0u;
       if ((dead0 | dead1) == 0) continue;
@@ -3507,9 +3539,9 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
       for (uint32_t k = 0; k < 4; ++k) {
         uint32_t gone = 0;
 #pragma unroll
-        for (uint32_t b = 0; b < 4; ++b) {                 // rank 4 k + b of the vector: byte 3 - b of word k
-          if ((dead0 >> (4 * k + b)) & 1u) gone |= (kNib ? 0x0Fu : 0xFFu) << (8 * (3 - b));
-          if ((dead1 >> (4 * k + b)) & 1u) gone |= 0xF0u << (8 * (3 - b));
+        for (uint32_t b = 0; b < 4; ++b) {                 // rank 4 k + b of the vector: byte 3 - b of word k (one window: nibble b / 4 + b)
+          if ((dead0 >> (4 * k + b)) & 1u) gone |= kNib1 ? 0xFu << (4 * b) : (kNib ? 0x0Fu : 0xFFu) << (8 * (3 - b));
+          if ((dead1 >> (4 * k + b)) & 1u) gone |= kNib1 ? 0xFu << (16 + 4 * b) : 0xF0u << (8 * (3 - b));
         }
         d[k] &= ~gone;
       }
@@ -3553,7 +3585,8 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
   // per lane and round: counters above c, counters AT c in the even / odd window
   const typename S::Need at_c = S::prepare(min(c, cap)), above_c = S::prepare(min(c + 1, S::kMaxCount));
   const bool has_above = c + 1 <= cap, none = c > cap;
-  constexpr uint32_t kEven = kNib ? 0x08080808u : 0x80808080u, kOdd = kNib ? 0x80808080u : 0u;   // a field's top bit, by window of the pair
+  // a field's top bit, by window of the pair (by half of the one window)
+  constexpr uint32_t kEven = kNib1 ? 0x00008888u : kNib ? 0x08080808u : 0x80808080u, kOdd = kNib1 ? 0x88880000u : kNib ? 0x80808080u : 0u;
   auto masks = [&](const uint32_t wv, uint32_t& up, uint32_t& tie) {
     const uint32_t r = none ? 0u : S::hits(wv, at_c);
     up = has_above ? S::hits(wv, above_c) : 0u;
@@ -3623,10 +3656,10 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
     for (uint32_t k = 0; k < 4; ++k) {
       uint32_t up, tie;
       masks(d[k], up, tie);
-      // ties in rank order: inside a word the byte positions DESCEND with the rank
+      // ties in rank order: inside a word the byte positions DESCEND with the rank (one window: the nibbles ascend)
       uint32_t m = at0 < quota ? tie & kEven : 0u;       // (behind the quota: nothing of this lane's any more)
       while (m) {
-        const uint32_t bit = 31u - __clz(m);
+        const uint32_t bit = kNib1 ? __ffs(m) - 1u : 31u - __clz(m);
         m &= ~(1u << bit);
         if (at0++ < quota) {
           const uint32_t pos = bit / P::kBits;
@@ -3636,7 +3669,7 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
       if (kNib) {
         m = at1 < quota ? tie & kOdd : 0u;
         while (m) {
-          const uint32_t bit = 31u - __clz(m);
+          const uint32_t bit = kNib1 ? __ffs(m) - 1u : 31u - __clz(m);
           m &= ~(1u << bit);
           if (at1++ < quota) {
             const uint32_t pos = bit / P::kBits;
@@ -3662,7 +3695,7 @@ template <typename CT, int NT>
 __device__ __forceinline__ void one_step(const FindArgs& A, const uint32_t T, const uint32_t code, uint32_t* cnt32,
                                          unsigned long long* pool, Control* ctl, OneShared* sh, const uint32_t w,
                                          const uint32_t w_end) {
-  constexpr bool kNib = std::is_same<CT, Nib>::value;
+  constexpr bool kNib = std::is_same<CT, Nib>::value;      // (Nib1: one window, like the byte counters)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t w_even = kNib ? (w & ~1u) : w;
   uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
@@ -3712,7 +3745,10 @@ struct OneArgs {
 //     limit 100: 2 us a pass);
 //   * one wave's prefix sums over the lists turn the places into the length of every list's passing prefix and its
 //     offset in the output; output slot i finds its (list, place) by a binary search over the offsets and loads that key.
-// Exactly min(keep, keys there are) keys arrive; compact_pool's rank count puts those few in order.
+// Exactly min(keep, keys there are) keys arrive, and are put in order by counting, for every key, the keys below it --
+// eight threads per key, each over an eighth of the keys, all of its reads in flight at once (compact_pool's rank count,
+// made for pools that change under a sweep, walks them in a dependent loop of two keys a read: 4 us for 100 keys on
+// the two waves that hold them).
 // (Through round 5's first version: the keys not above the keep-th smallest list head, and of those the ones at place p
 // of a list with r smaller heads in front where r + p < keep -- up to keep (keep + 1) / 2 keys, sorted by compact_pool's
 // bitonic network: 32 us at Geonames scale and limit 100, 64 us on a haystack of massive ties, of a find's 70 and 104.
@@ -3731,12 +3767,14 @@ __device__ __forceinline__ void one_merge(const FindArgs& A, const unsigned long
   unsigned long long* const pool = reinterpret_cast<unsigned long long*>(w32);   // [kOnePool]
   uint32_t* const below = w32 + 2 * kOnePool;                          // [128] keys of a level below l, l = 1 .. T
   uint32_t* const off = below + 128;                                   // [kOneMaxGrid] where a list's passing prefix starts in the output
-  unsigned char* const reach = reinterpret_cast<unsigned char*>(off + kOneMaxGrid);   // [65][kOneMaxGrid] the place where a list's levels reach l
+  uint32_t* const place = off + kOneMaxGrid;                           // [128] an arriving key's place in the output order
+  unsigned char* const reach = reinterpret_cast<unsigned char*>(place + 128);   // [65][kOneMaxGrid] the place where a list's levels reach l
   unsigned char* const lvl = reach + 65 * kOneMaxGrid;                 // [G * keep] a slot's level
-  static_assert((2 * kOnePool + 128 + kOneMaxGrid) * 4 + 65 * kOneMaxGrid + kOneMaxGrid * kOneMaxKeep <= kWindowSize &&
-                kOnePool >= kOneMaxKeep && kOneMaxKeep < 256, "merge scratch");
+  static_assert((2 * kOnePool + 128 + kOneMaxGrid + 128) * 4 + 65 * kOneMaxGrid + kOneMaxGrid * kOneMaxKeep <= kWindowSize &&
+                kOnePool >= kOneMaxKeep && kOneMaxKeep <= 128 && NT % 128 == 0, "merge scratch");
   const uint32_t own0 = g * keep, total = G * keep;                    // (this workgroup's own list -- the last -- comes from its pool)
   if (tid == 0) { ctl->pool_n = 0; ctl->overflow = 0; ctl->thr = kKeyInf; ctl->adm_n = 0; }
+  if (tid < 128) place[tid] = 0;
   auto slot = [&](const uint32_t idx) -> unsigned long long {
     if (idx < own0) return __hip_atomic_load(&part_keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return idx - own0 < nres ? s_pool[idx - own0] : kKeyInf;
@@ -3821,6 +3859,23 @@ __device__ __forceinline__ void one_merge(const FindArgs& A, const unsigned long
     pool[tid] = slot(lo * keep + (tid - off[lo]));
   }
   __syncthreads();
+  ONE_MARK(A, 15);
+  {
+    constexpr uint32_t kParts = NT / 128, kShare = 128 / kParts;
+    const uint32_t i = tid & 127u, first = (tid >> 7) * kShare;
+    const unsigned long long mine = i < n_out ? pool[i] : kKeyInf;
+    uint32_t lower = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kShare; ++j)
+      if (first + j < n_out) lower += pool[first + j] < mine ? 1u : 0u;   // (one address per wave and read: broadcasts)
+    if (i < n_out && lower) atomicAdd(&place[i], lower);
+    __syncthreads();
+    const unsigned long long key = tid < n_out ? pool[tid] : kKeyInf;
+    const uint32_t to = tid < n_out ? place[tid] : 0u;
+    __syncthreads();
+    if (tid < n_out) pool[to] = key;                     // (keys are distinct: the places are a permutation)
+    __syncthreads();
+  }
 }
 
 template <int NT>
@@ -3854,7 +3909,8 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
     // needle the leading windows whose references have at most 15 (nib_windows: an even count) -- find_kernel's rule
     if (T <= 15 || w < A.nib_windows) {
       const uint32_t w_end = min(w1, (w | 1u) + 1u);
-      one_step<Nib, NT>(A, T, code, s_counters, s_pool, ctl, &s_sh, w, w_end);
+      if (w_end - w == 1) one_step<Nib1, NT>(A, T, code, s_counters, s_pool, ctl, &s_sh, w, w_end);   // (a single window: 32 KiB)
+      else one_step<Nib, NT>(A, T, code, s_counters, s_pool, ctl, &s_sh, w, w_end);
       w = w_end;
     } else {
       one_step<uint8_t, NT>(A, T, code, s_counters, s_pool, ctl, &s_sh, w, w + 1);
@@ -3890,9 +3946,8 @@ __global__ __launch_bounds__(NT) void find_one_kernel(const FindArgs A, const On
     } while (pending);
   }
   ONE_MARK(A, 9);
-  one_merge<NT>(A, part_keys, s_counters, s_pool, ctl, nres, T, keep, g, G);
+  one_merge<NT>(A, part_keys, s_counters, s_pool, ctl, nres, T, keep, g, G);   // (leaves the keys in order, ctl->pool_n of them)
   unsigned long long* const pool = reinterpret_cast<unsigned long long*>(s_counters);
-  compact_pool<NT>(pool, ctl, kOnePool, keep);
   ONE_MARK(A, 12);
   const uint32_t n_out = ctl->pool_n;
   if (tid < n_out) {

@@ -31,10 +31,11 @@ for nd in needles:
     base = t[:, 0].min()
     us = (t - base) / 100.0
     last = int(np.argmax(t[:, 10]))                      # the merging workgroup wrote mark 10
-    row = [np.median(us[:, i]) for i in range(10)] + [us[:, i].max() for i in range(10)] + [us[last, i] for i in range(10, 15)] + [host]
+    row = [np.median(us[:, i]) for i in range(10)] + [us[:, i].max() for i in range(10)] + [us[last, i] for i in range(10, 15)] + [host] + [us[last, 15]]
     acc.append(row)
 a = np.median(np.array(acc), axis=0)
 print(f"{wl}: {G} workgroups, limit {limit}; microseconds from the first workgroup's start (median over {len(needles)} needles)")
 for i in range(10): print(f"  {names[i]:12s} median wg {a[i]:6.2f}   last wg {a[10 + i]:6.2f}")
 for i in range(10, 15): print(f"  {names[i]:12s} merging wg {a[10 + i]:6.2f}")
+print(f"  m:gathered   merging wg {a[26]:6.2f}   (between m:H+filter and m:sorted)")
 print(f"  host clock around the call {a[25]:.1f} us")
