@@ -91,6 +91,17 @@ def test_full_geonames_scale_properties(geonames_full):
     o = geonames_full.oracle
     for nd, rows in list(zip(needles, got))[1990:2030]:
         assert rows == o.find(nd, limit), nd
+    # the single find at this scale -- 129 workgroups, one list each, merged by find_one_kernel's last workgroup
+    # (one_merge: up to 129 x 120 slots) -- at the limits where the lists are long
+    taken = m.get_option("one_taken")
+    longest = max((x for x in strings if len(Oracle.tokenise(x)) <= 64), key=lambda x: len(Oracle.tokenise(x)))   # many levels
+    singles = needles[1996:2007] + [longest]
+    for lim in (10, 100, 120):
+        for nd in singles:
+            out = np.zeros((lim, 3), dtype=np.uint32)
+            k = m._lib.blurrily_storage_find(m.handle, nd, lim, out.ctypes.data)
+            assert out[:k].tolist() == o.find(nd, lim), (nd, lim)
+    assert m.get_option("one_taken") - taken == 3 * len(singles)
 
 
 def test_full_skewed_scale_properties():
@@ -114,6 +125,12 @@ def test_full_skewed_scale_properties():
     o.put_many(hay, off)
     for nd, rows in list(zip(needles, got))[:24]:
         assert rows == o.find(nd, limit), nd
+    # ... and the single find on this haystack of massive ties (62 lists of up to 120 keys of a handful of levels)
+    for lim in (100, 120, 7):
+        for nd in needles[:8]:
+            out = np.zeros((lim, 3), dtype=np.uint32)
+            k = m._lib.blurrily_storage_find(m.handle, nd, lim, out.ctypes.data)
+            assert out[:k].tolist() == o.find(nd, lim), (nd, lim)
 
 
 def test_config2_words_100k_batch():
