@@ -42,7 +42,19 @@ Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carr
                  points on configs[2]'s kind of haystack: `geonames_x4` -- four times the strings, an
                  image seven times the 256 MiB Infinity Cache, i.e. the one point whose bytes are HBM
                  bytes -- and `geonames_miss` -- needles from a foreign vocabulary, without a close
-                 match, so that the threshold stays low.  A few steps each, same fields.
+                 match, so that the threshold stays low.  A few steps each, same fields.  `dict_words`:
+                 /usr/share/dict/words itself where the box has it (SHA-256 recorded), else a note that
+                 `words` is its seeded stand-in.  `published_curve`: the reference's own published
+                 benchmark (doc/bench.numbers: single-find latency on six dataset sizes, eight fixed
+                 needles, limit 10) -- p50 of blurrily_storage_find (one launch, no copy) beside the
+                 compiled reference on one core of this box, all 48 answers compared row for row.
+  p50_query_us   the other half of BASELINE.json's metric: host clock around blurrily_storage_find.
+
+`roofline.bound` says what the profiles support: "hbm" only where the image exceeds the L2 and the rate
+reaches 0.6 of the peak; otherwise "latency chain" (the step's dependent LDS round trips and barriers,
+DESIGN.md section 5) with `nearest_roof` and, for an image that lives in L2, the L2 fraction beside it.
+`--scaling strong` (N > 1) splits configs[3]'s literal 8 M-needle batch over the ranks instead of giving
+each its own 1 M; `n_gpus` counts DISTINCT physical devices (`distinct_devices`, by UUID / PCI bus id).
 
 A leg that fails -- the CPU baseline, an extra config, a parity comparison -- is recorded in the line
 AND makes the exit status 1: a line without its baseline is not a result.
