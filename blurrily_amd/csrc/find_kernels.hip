@@ -3537,11 +3537,22 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
       uint32_t d[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
-        uint32_t gone = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 4; ++b) {                 // rank 4 k + b of the vector: byte 3 - b of word k (one window: nibble b / 4 + b)
-          if ((dead0 >> (4 * k + b)) & 1u) gone |= kNib1 ? 0xFu << (4 * b) : (kNib ? 0x0Fu : 0xFFu) << (8 * (3 - b));
-          if ((dead1 >> (4 * k + b)) & 1u) gone |= kNib1 ? 0xFu << (16 + 4 * b) : 0xF0u << (8 * (3 - b));
+        // rank 4 k + b of the vector is dead: byte 3 - b of word k goes (one window: nibble b, and 4 + b for the upper
+        // half).  The four bits of a word are spread by arithmetic -- no table of masks, which the compiler would keep
+        // in registers for the kernel's life (that was the kernel's one spilled VGPR).
+        const uint32_t n0 = (dead0 >> (4 * k)) & 0xFu, n1 = (dead1 >> (4 * k)) & 0xFu;
+        uint32_t gone;
+        if (kNib1) {
+          auto nibbles = [](uint32_t n) {                // bit b -> bit 4 b
+            n = (n | (n << 6)) & 0x0303u;
+            return (n | (n << 3)) & 0x1111u;
+          };
+          gone = (nibbles(n0) | (nibbles(n1) << 16)) * 0xFu;
+        } else {
+          auto bytes = [](uint32_t n) {                  // bit b -> bit 8 (3 - b): reversed, then bit j -> bit 8 j (no two partial products meet)
+            return ((__brev(n) >> 28) * 0x00204081u) & 0x01010101u;
+          };
+          gone = kNib ? bytes(n0) * 0x0Fu | bytes(n1) * 0xF0u : bytes(n0) * 0xFFu;
         }
         d[k] &= ~gone;
       }

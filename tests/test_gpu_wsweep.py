@@ -76,12 +76,19 @@ def _mixed_needles(hay, off, n_q, seed):
     return _pack([needles[i] for i in order])
 
 
-@pytest.mark.parametrize("limit,cmin", [(10, 2), (10, 1), (10, 3), (100, 2), (128, 2), (1, 2), (3, 2)])
-def test_geonames_medium_all_rows_vs_oracle(limit, cmin):
+@pytest.fixture(scope="module")
+def medium():
     hay, off = W.geonames(600000, 80000, 41)                   # 10 windows
     m, o = _pair(hay, off)
-    _ws(m, ws_min_windows=4, ws_min_needles=1000, ws_cmin=cmin)
     packed, offs = _mixed_needles(hay, off, 6000, 42)
+    yield m, o, packed, offs
+    m.close()
+
+
+@pytest.mark.parametrize("limit,cmin", [(10, 2), (10, 1), (10, 3), (100, 2), (128, 2), (1, 2), (3, 2)])
+def test_geonames_medium_all_rows_vs_oracle(limit, cmin, medium):
+    m, o, packed, offs = medium                                # (one image, one oracle: "ws_cmin" is read per find)
+    _ws(m, ws_min_windows=4, ws_min_needles=1000, ws_cmin=cmin)
     _check_all(m, o, packed, offs, limit)
 
 
