@@ -2451,6 +2451,32 @@ __device__ __forceinline__ void ws_bump8_cross(uint32_t* cnt32, const uint4 v, u
     if (bfe4_low5(old_hi[j], sh_hi[j]) == was && (d[j] >> 16) < wlen) ws_push_cand(cand, n_cand, cand_ov, d[j] >> 16);
   }
 }
+// The same returning atomics for a COLD window (no threshold yet): a counter passes every value once, so the number of
+// increments that produce the value m IS the number of counters that reach m -- counted here, in hist[m] (m >= 2: one
+// LDS atomic for the few postings that find their counter already at work), the cold start needs no pass over the
+// counters at all to know the largest bound that `keep` of them reach.  Padding (rank 0xFFFF) is not a counter.
+__device__ __forceinline__ void ws_bump8_hist(uint32_t* cnt32, const uint4 v, uint32_t* hist) {
+  if (!group_live(v)) return;
+  unsigned char* const base = reinterpret_cast<unsigned char*>(cnt32);
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+  uint32_t old_lo[4], old_hi[4], sh_lo[4], sh_hi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                              // eight returning atomics in flight
+    const uint32_t x = d[j] & 0x8003u, y = d[j] & 0x80030000u;
+    sh_lo[j] = (x << 2) + (x >> 11);
+    sh_hi[j] = (y >> 14) | (y >> 27);
+    old_lo[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + (d[j] & 0x7FFCu)), one_shl_low5(sh_lo[j]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old_hi[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + ((d[j] >> 16) & 0x7FFCu)), one_shl_low5(sh_hi[j]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t was_lo = bfe4_low5(old_lo[j], sh_lo[j]), was_hi = bfe4_low5(old_hi[j], sh_hi[j]);
+    if (was_lo != 0 && (d[j] & 0xFFFFu) != kPadRank) atomicAdd(&hist[was_lo + 1], 1u);
+    if (was_hi != 0 && (d[j] >> 16) != kPadRank) atomicAdd(&hist[was_hi + 1], 1u);
+  }
+}
 // one posting into the half-window byte layout: rank r of half `h` -> byte r & 0x7FFF; a posting of the
 // other half goes to a dump word behind the counters
 __device__ __forceinline__ void ws_bump_byte(uint32_t* cnt32, uint32_t r, uint32_t h) {
@@ -3086,6 +3112,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   __shared__ unsigned long long s_pool[kWsPool];
   __shared__ Control s_ctl;
   __shared__ uint32_t s_tally[8];                        // the cold start's tallies, one per pass of the search
+  __shared__ uint32_t s_hist[16];                        // a cold window's counters that reach m, m = 2 .. 15 (ws_bump8_hist)
+  constexpr bool kSmallHist = true;
   __shared__ uint32_t s_nextq[2];                        // the queue slot popped for the needle after the current one, by that needle's parity
   __shared__ uint32_t s_cand[kSmallCand];                // a window's counters at the bound: in-window rank | count << 16
   __shared__ uint32_t s_ncand;
@@ -3097,6 +3125,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   constexpr uint32_t kVecs = kWsCntWords / 4 / kWsNT;    // a thread's vectors of the window's counters: eight
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   if (tid < 8) s_tally[tid] = 0;
+  if (tid < 16) s_hist[tid] = 0;
   if (tid == 0) s_ncand = 0;
   uint32_t st_ent = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0, st_tab = 0;
   ws_barrier();
@@ -3204,21 +3233,29 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
         ++st_steps;
         // ---- count: unit j of slice t belongs to wave (t + j) mod 4; the first two are here already (or loaded now),
         // the others are loaded and counted in place, one unit's atomics under the next one's load
+        const bool cold = thr == kKeyInf && T > 1 && !A.tomb;    // no threshold yet: the window's own bound first
         {
           if (!head_ok) SMALL_LOAD_HEAD(ta, tb);
           head_ok = false;
-          uint32_t k = 0;
-          uint4 pend = h1;
-          ws_bump8<false>(s_cnt, h0, 0u);
-          BLURRILY_FOR_SLOT_UNITS(kWsNW, ta, tb, wid, lane, k, {
-            if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8));
-            if (k >= 2) {
-              const uint4 v = load_group(A.ent, c, sb);
-              ws_bump8<false>(s_cnt, pend, 0u);
-              pend = v;
-            }
-          });
-          ws_bump8<false>(s_cnt, pend, 0u);
+          auto count = [&](auto hist_too) {
+            constexpr bool kHist = decltype(hist_too)::value;
+            auto bump = [&](const uint4 grp) { if (kHist) ws_bump8_hist(s_cnt, grp, s_hist); else ws_bump8<false>(s_cnt, grp, 0u); };
+            // (the wave's third unit requested BEFORE the two that are here are counted, so that its load travels under
+            // both -- measured: 3.25 -> 3.43 ms per 100 k needles; the walk to the third unit delays the first atomics)
+            uint32_t k = 0;
+            uint4 pend = h1;
+            bump(h0);
+            BLURRILY_FOR_SLOT_UNITS(kWsNW, ta, tb, wid, lane, k, {
+              if (STATS(A)) st_ent += min(512u, sb - (c - lane * 8));
+              if (k >= 2) {
+                const uint4 v = load_group(A.ent, c, sb);
+                bump(pend);
+                pend = v;
+              }
+            });
+            bump(pend);
+          };
+          if (kSmallHist && cold) count(std::true_type{}); else count(std::false_type{});
         }
         if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 2u);
         // the next window's first units go out now: they travel under this window's scan
@@ -3247,8 +3284,15 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
         if (tid == 0 && Y0.nv < kWsCntWords / 4) s_cnt[kWsCntWords - 1] = 0;   // the padding slot's word (a short window)
         if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 5u);
         uint32_t floor_need = need;
-        if (thr == kKeyInf && T > 1 && !A.tomb) {
-          // no threshold yet: only counters that can be among the window's best `keep` (cold_start_need's argument)
+        if (kSmallHist && cold) {
+          // no threshold yet: only counters that can be among the window's best `keep` (cold_start_need's argument) -- the
+          // largest m that `keep` counters reach, read off the count's own histogram (through round 5: a bisection over
+          // the counters in registers, a pass and a barrier per probe: 7 800 of a needle's 78 800 clocks)
+          PATH_FLAG(A, q, kPathColdStart);
+          const uint32_t reach_m = lane >= 2 && lane < 16 ? s_hist[lane] : 0u;
+          const unsigned long long ok = __ballot(lane >= 2 && lane <= min(T, 15u) && reach_m >= keep);
+          if (ok) floor_need = max(floor_need, 63u - uint32_t(__builtin_clzll(ok)));
+        } else if (cold) {
           PATH_FLAG(A, q, kPathColdStart);
           uint32_t lo = 1, hi = min(T, 15u), pass = 0;
           while (lo < hi) {
@@ -3303,6 +3347,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
             }
           }
           ws_barrier();
+          if (kSmallHist && cold && tid < 16) s_hist[tid] = 0;   // (everyone has read it: ready for the next cold count)
           const uint32_t n_cand = s_ncand;
           if (n_cand <= kSmallCand) {
             for (uint32_t c2 = tid; c2 < n_cand; c2 += kWsNT) {
