@@ -3116,7 +3116,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   constexpr bool kSmallHist = true;
   __shared__ uint32_t s_nextq[2];                        // the queue slot popped for the needle after the current one, by that needle's parity
   __shared__ uint32_t s_cand[kSmallCand];                // a window's counters at the bound: in-window rank | count << 16
-  __shared__ uint32_t s_ncand;
+  __shared__ uint32_t s_ncand[2];                        // its length, by the harvest's parity (the other slot is reset meanwhile: no barrier for that)
   uint4* cnt128 = reinterpret_cast<uint4*>(s_cnt);
   Control* ctl = &s_ctl;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -3126,7 +3126,8 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   if (tid < 8) s_tally[tid] = 0;
   if (tid < 16) s_hist[tid] = 0;
-  if (tid == 0) s_ncand = 0;
+  if (tid < 2) s_ncand[tid] = 0;
+  uint32_t hp = 0;                                       // the harvest's parity
   uint32_t st_ent = 0, st_steps = 0, st_redo = 0, st_tasks = 0, st_compact = 0, st_tab = 0;
   ws_barrier();
   // The NEXT needle is set up while the current one is swept -- its queue pop, its scalars, its codes, its first slice
@@ -3328,7 +3329,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
             if (((v[j].x | v[j].y | v[j].z | v[j].w) & Y.pre) != 0)
               n_hit += __popc(Y.hits(v[j].x)) + __popc(Y.hits(v[j].y)) + __popc(Y.hits(v[j].z)) + __popc(Y.hits(v[j].w));
           if (n_hit) {
-            uint32_t at = atomicAdd(&s_ncand, n_hit);
+            uint32_t at = atomicAdd(&s_ncand[hp], n_hit);
             if (at + n_hit <= kSmallCand) {
 #pragma unroll
               for (uint32_t j = 0; j < kVecs; ++j) {
@@ -3348,7 +3349,9 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
           }
           ws_barrier();
           if (kSmallHist && cold && tid < 16) s_hist[tid] = 0;   // (everyone has read it: ready for the next cold count)
-          const uint32_t n_cand = s_ncand;
+          const uint32_t n_cand = s_ncand[hp];
+          if (tid == 0) s_ncand[hp ^ 1u] = 0;            // (the harvest before this one is done with it)
+          hp ^= 1u;
           if (n_cand <= kSmallCand) {
             for (uint32_t c2 = tid; c2 < n_cand; c2 += kWsNT) {
               const uint32_t e2 = s_cand[c2];
@@ -3372,8 +3375,6 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
               }
             }
           }
-          ws_barrier();                                  // (everyone has read the list's length)
-          if (tid == 0) s_ncand = 0;
         }
         ws_barrier();
         if (wid == 0) TRACE_MARK_AT(A, 50000u, q, i, 0u, 7u);
