@@ -2514,7 +2514,8 @@ __device__ __forceinline__ void ws_compact_pool(unsigned long long* pool, Contro
   if (tid < n) {
     uint32_t j = n_sorted;                                              // (same address in every lane: broadcasts)
     if (j & 1u) { if (j < n) below += pool[j] < mine; ++j; }
-    for (; j + 2 <= n; j += 2) {                                        // two keys per read
+#pragma unroll 4
+    for (; j + 2 <= n; j += 2) {                                        // two keys per read (four reads in flight)
       const ulonglong2 two = *reinterpret_cast<const ulonglong2*>(pool + j);
       below += uint32_t(two.x < mine) + uint32_t(two.y < mine);
     }
