@@ -3122,7 +3122,7 @@ __global__ __launch_bounds__(kWsNT, kWsNT / 64) void find_small_kernel(const Fin
   Control* ctl = &s_ctl;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t keep = A.keep;
-  const uint32_t sel_at = min(keep + max(6u, keep / 2), kWsPool / 2);
+  const uint32_t sel_at = min(keep + max(6u, keep / 2), kWsPool / 2);   // (3 keep + 6, 6 keep + 6: 3.13 -> 3.16 ms per 100 k needles at configs[1])
   constexpr uint32_t kVecs = kWsCntWords / 4 / kWsNT;    // a thread's vectors of the window's counters: eight
   for (uint32_t i = tid; i < (kWsCntWords + 4) / 4; i += kWsNT) cnt128[i] = make_uint4(0, 0, 0, 0);
   if (tid < 8) s_tally[tid] = 0;
@@ -3633,6 +3633,10 @@ __device__ __forceinline__ void one_select(const FindArgs& A, uint4* cnt128, con
   } else if (tally(lo) < keep) {
     all = true;
   } else {
+    // (The bound read off a histogram the COUNT keeps -- find_small_kernel's cold start, ws_bump8_hist, a row per wave --
+    // measured here: median workgroup's count 3.2 -> 3.8 us, the SLOWEST's count barrier 5.0 -> 8.2 us -- windows where
+    // thousands of postings meet a counter at work queue on a handful of histogram words -- and the find's p50 28.4 ->
+    // 31.5 us, p90 33 -> 89.  The bisection's five passes cost every workgroup the same 3 us; left as it is.)
     while (lo < hi) {                                    // (at most seven passes with byte counters, four with 4-bit ones)
       const uint32_t mid = (lo + hi + 1) >> 1;
       if (tally(mid) >= keep) lo = mid; else hi = mid - 1;
