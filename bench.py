@@ -122,9 +122,16 @@ def kernel_source_hash():
     launch logic are built from: what a PMC profile must have been taken at to describe this run."""
     import hashlib
     h = hashlib.sha256()
+    import re
+    src = os.path.join(ROOT, "blurrily_amd", "csrc")
+
+    def text_of(f):
+        """a source with its `#include "kernels/..."` lines replaced by what they include (find_kernels.hip is one
+        translation unit kept in several files: moving code between them does not change what is compiled)"""
+        with open(os.path.join(src, f), "r", encoding="utf-8") as fh:
+            return re.sub(r'^#include "(kernels/[\w.]+)"$', lambda m: text_of(m.group(1)), fh.read(), flags=re.M)
     for f in ("find_kernels.hip", "find_kernels.h", "device_index.hip", "device_index.h", "c_abi.hip"):
-        with open(os.path.join(ROOT, "blurrily_amd", "csrc", f), "r", encoding="utf-8") as fh:
-            h.update(code_only(fh.read()).encode("utf-8"))
+        h.update(code_only(text_of(f)).encode("utf-8"))
     return h.hexdigest()[:16]
 # LDS atomics: no-return ds_add_u32 lanes per second, whole chip, MEASURED (tools/micro/lds_atomic_rate.hip,
 # profiles/r02_lds_atomic_rate.txt: conflict-free addresses, find_kernel's residency; 6.97e12 with random

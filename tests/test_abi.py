@@ -71,7 +71,9 @@ def test_the_library_never_reads_the_environment():
     # ... and the kernel source carries two build switches and no experiment switches: the counted build, and the TRACE
     # build of the timed kernels (shader-clock stamps of a few needles' steps for tools/trace_steps.py; it compiles to
     # nothing in the library that ships)
-    src = open(os.path.join(ROOT, "blurrily_amd", "csrc", "find_kernels.hip")).read()
+    csrc = os.path.join(ROOT, "blurrily_amd", "csrc")
+    src = open(os.path.join(csrc, "find_kernels.hip")).read()
+    src += "".join(open(os.path.join(csrc, "kernels", f)).read() for f in sorted(os.listdir(os.path.join(csrc, "kernels"))))
     switches = set(re.findall(r"^#\s*if(?:n?def)?\s+!?\s*(?:defined\s*\(\s*)?(\w+)", src, flags=re.M))
     assert switches == {"BLURRILY_COUNTED", "BLURRILY_TRACE"}, switches
 

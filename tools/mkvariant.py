@@ -9,6 +9,7 @@ d = os.path.join(root, "blurrily_amd", "csrc_x" + name)
 shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
 for f in glob.glob(os.path.join(root, "blurrily_amd", "csrc", "*")):
     if os.path.isfile(f) and not f.endswith(".s"): shutil.copy(f, d)
+shutil.copytree(os.path.join(root, "blurrily_amd", "csrc", "kernels"), os.path.join(d, "kernels"))   # (EDITS name them as kernels/x.inc)
 ns = {}; exec(open(edits).read(), ns)
 for f, old, new in ns["EDITS"]:
     p = os.path.join(d, f); s = open(p).read()
