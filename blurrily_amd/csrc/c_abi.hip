@@ -138,6 +138,7 @@ struct trigram_map_t {
   size_t      watch_n[6] = {0, 0, 0, 0, 0, 0};
   float       tuned_us_per_needle[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // of the sweep that was chosen
   uint32_t    retune_holdoff[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t    watch_strikes[6] = {0, 0, 0, 0, 0, 0};   // consecutive batches of the class seen slow (one is noise: another tenant, a clock step)
   uint64_t    retunes = 0;              // classes measured again because a batch ran slow (option "retunes", read-only)
   int         tune_inject = 0;          // (tests) the next measurement sees this sweep at HALF its time: a bad sample to recover from
   int         n_cus = 0;
@@ -527,9 +528,14 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         if (hipEventElapsedTime(&ms, m->watch_ev[cls][0], m->watch_ev[cls][1]) == hipSuccess && m->watch_n[cls] &&
             m->tuned_us_per_needle[cls] > 0.f && m->ws_choice[cls] != 0) {
           const float us = 1000.f * ms / float(m->watch_n[cls]);
-          if (us > 1.10f * m->tuned_us_per_needle[cls] && m->retune_holdoff[cls] == 0) {
+          // (TWO batches in a row: a single slow one -- seen on a shared box, 2.3 x inside bench.py's three timed steps --
+          // would put a measurement of every sweep, twice, into a batch that had nothing wrong)
+          if (us <= 1.10f * m->tuned_us_per_needle[cls]) {
+            m->watch_strikes[cls] = 0;
+          } else if (++m->watch_strikes[cls] >= 2 && m->retune_holdoff[cls] == 0) {
             m->ws_choice[cls] = 0;                     // measured again, below
             m->retune_holdoff[cls] = 16;
+            m->watch_strikes[cls] = 0;
             ++m->retunes;
           }
         }

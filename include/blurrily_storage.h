@@ -253,8 +253,8 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *                             -- TWICE, the better run counting (same rows; that one call waits for them, see
  *                             blurrily_storage_tune) and the fastest serves the class until the image is rebuilt or an
  *                             option changes; leaving slices out has to win by 3 %, the window-major sweep by 5 %.  The
- *                             choice is watched: a later batch of the class that runs over 10 % slower per needle than
- *                             the measurement saw has the class measured again, at most once in sixteen batches
+ *                             choice is watched: two batches of the class in a row that run over 10 % slower per needle
+ *                             than the measurement saw have the class measured again, at most once in sixteen batches
  *                             ("retunes", get: how often that happened).  0: the static rules below
  *   "ws_static_slice" (2200)  the static rule: window-major iff mean postings per window >= this, x1.7 for batches
  *                             under 65 536 needles, x1.7 for limits above 32, x4 for both (measured table)
