@@ -123,9 +123,9 @@ struct trigram_map_t {
   uint32_t    ws_min_needles = 16384;   // smaller batches: needle-major
   bool        ws_autotune = true;       // measure the choice per class of batch on first use (run_find_on)
   uint32_t    ws_static_slice = 2200;   // the static rule's mean_hit_slice (autotune off): break-even of the skewed family
-  int         ws_choice[6] = {0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major,
+  int         ws_choice[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per class: 0 not measured yet, 1 needle-major, 2 window-major,
                                                    // 3 needle-major with slices left out
-  float       ws_tuned_ms[6][3] = {};   // what the measurement saw (needle-major, window-major, slices left out)
+  float       ws_tuned_ms[8][3] = {};   // what the measurement saw (needle-major, window-major, slices left out)
   int         last_tuned = -1;          // the class measured most recently ("tuned_*_us" report its figures)
   int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2 / 3; 0: none yet)
   size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
@@ -133,12 +133,12 @@ struct trigram_map_t {
   // a measured choice is WATCHED: the chosen sweep's later batches of the class are bracketed by two events (read at the
   // class's next batch, never waited for); one that ran over 10 % slower per needle than what the measurement saw has
   // the class measured again -- at most once in sixteen batches
-  hipEvent_t  watch_ev[6][2] = {};
-  bool        watch_pending[6] = {false, false, false, false, false, false};
-  size_t      watch_n[6] = {0, 0, 0, 0, 0, 0};
-  float       tuned_us_per_needle[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // of the sweep that was chosen
-  uint32_t    retune_holdoff[6] = {0, 0, 0, 0, 0, 0};
-  uint32_t    watch_strikes[6] = {0, 0, 0, 0, 0, 0};   // consecutive batches of the class seen slow (one is noise: another tenant, a clock step)
+  hipEvent_t  watch_ev[8][2] = {};
+  bool        watch_pending[8] = {false, false, false, false, false, false, false, false};
+  size_t      watch_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float       tuned_us_per_needle[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // of the sweep that was chosen
+  uint32_t    retune_holdoff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t    watch_strikes[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // consecutive batches of the class seen slow (one is noise: another tenant, a clock step)
   uint64_t    retunes = 0;              // classes measured again because a batch ran slow (option "retunes", read-only)
   int         tune_inject = 0;          // (tests) the next measurement sees this sweep at HALF its time: a bad sample to recover from
   int         n_cus = 0;
@@ -492,7 +492,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // (at the same mean_hit_slice one family of haystacks wins 1.4x with the window-major sweep
     // where another loses 0.7x; leaving slices out wins 14 % on a haystack four times Geonames scale, 3 % at
     // Geonames scale, and LOSES 9 % there on needles without a close match), so the choice is MEASURED: the first
-    // batch of a class -- limit up to / above 32, by batch size 16 384.. / 65 536.. / 262 144.. -- on an image runs
+    // batch of a class -- limit up to / above 32, by batch size 1 024.. / 16 384.. / 65 536.. / 262 144.. -- on an image runs
     // every sweep it can take (they give the same rows; that one call waits for them), the plain sweep twice -- the
     // first run of all meets cold caches -- and the fastest serves the class until the image is rebuilt or an option
     // changes; a sweep other than the plain one has to win by 1.5 % (window-major: 5 %, it pays a launch per window).
@@ -519,8 +519,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       const double slice_factor = (n_cls < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
       const int static_choice = ws_possible && ix.mean_hit_slice >= slice_factor * double(m->ws_static_slice) ? 2
                                 : leave_possible && ix.n_windows >= m->nm_min_windows ? 3 : 1;
-      const int cls = (limit > 32 ? 3 : 0) + (n_cls < 65536 ? 0 : n_cls < 262144 ? 1 : 2);
-      const bool tunable = m->ws_autotune && is_base && n_cls >= 16384 && (leave_possible || ws_possible);
+      // (classes 6 and 7: batches of 1 024 .. 16 383 needles -- a server's coalesced FINDs; at Geonames scale leaving slices
+      // out wins there as it does on large batches: 0.9 -> 0.8 ms for 1 024 needles, 2.6 -> 2.1 for 4 096, 6.4 -> 5.4 for
+      // 12 000, which the static rule -- from 256 windows on -- gave away through round 5's first half)
+      const int cls = n_cls < 16384 ? (limit > 32 ? 7 : 6) : (limit > 32 ? 3 : 0) + (n_cls < 65536 ? 0 : n_cls < 262144 ? 1 : 2);
+      const bool tunable = m->ws_autotune && is_base && n_cls >= 1024 && (leave_possible || ws_possible);
       // what the class's last batch took, if it has finished (never waited for): slow against the measurement?
       if (tunable && !cb && m->watch_pending[cls] && hipEventQuery(m->watch_ev[cls][1]) == hipSuccess) {
         float ms = 0.f;
@@ -755,12 +758,12 @@ int ensure_replicas(trigram_map m) {
     s->build_opt = m->build_opt; s->ws_cmin = m->ws_cmin; s->nm_cmin = m->nm_cmin; s->nm_dense = m->nm_dense;
     s->ws_min_needles = m->ws_min_needles; s->ws_autotune = m->ws_autotune; s->ws_static_slice = m->ws_static_slice;
     s->nm_min_windows = m->nm_min_windows; s->small_sweep = m->small_sweep; s->small_min_needles = m->small_min_needles;
-    for (int c = 0; c < 6; ++c) if (m->ws_choice[c]) s->ws_choice[c] = m->ws_choice[c];
+    for (int c = 0; c < 8; ++c) if (m->ws_choice[c]) s->ws_choice[c] = m->ws_choice[c];
     s->n_cus = 0;
     if (r.base_builds != m->base_builds || s->dev.device < 0) {
       if (device_index_clone(m->dev, r.device, &s->dev) < 0) return -1;
       std::fill(std::begin(s->ws_choice), std::end(s->ws_choice), 0);
-      for (int c = 0; c < 6; ++c) s->ws_choice[c] = m->ws_choice[c];
+      for (int c = 0; c < 8; ++c) s->ws_choice[c] = m->ws_choice[c];
       r.base_builds = m->base_builds;
       r.log_version = ~0ull;                                   // (tombstones and totals below)
       r.delta_image_version = ~0ull;
@@ -1593,7 +1596,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 8: *value = m->ws_static_slice; return 0;
     case 9: {                                            // what was measured so far: class c's choice in bits 2c+1:2c
       long long v = 0;                                   // (1 needle-major, 2 window-major, 3 needle-major with slices left out)
-      for (int c = 0; c < 6; ++c) v |= (long long)(m->ws_choice[c]) << (2 * c);
+      for (int c = 0; c < 8; ++c) v |= (long long)(m->ws_choice[c]) << (2 * c);
       *value = v;
       return 0;
     }

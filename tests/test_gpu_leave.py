@@ -206,3 +206,31 @@ def test_a_bad_first_sample_of_the_measured_choice_is_corrected(geonames_full):
     assert m.get_option("last_sweep") == clean and m.get_option("retunes") == 1
     assert np.array_equal(counts, counts0) and np.array_equal(rows, rows0)
     m.close()
+
+
+def test_mid_size_batches_have_their_sweep_measured_too():
+    """Batches of 1 024 .. 16 383 needles -- a server's coalesced FINDs -- are a class of their own (6; 7 above limit 32)
+    whose first batch measures the sweeps like a large one's (c_abi.hip: run_find_on); smaller batches keep the static
+    rule.  Same rows whatever is chosen."""
+    hay, off = W.geonames(700000, 90000, 51)                   # 11 windows: the static rule alone would never leave a slice out
+    n = len(off) - 1
+    m, o = RawMap(), Oracle()
+    m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
+    o.put_many(hay, off)
+    q, qo = W.queries(hay, off, 3000, 71)
+    assert m.get_option("ws_choice") == 0
+    rows, counts = m.find_batch_packed(q, qo, 10)
+    picked = (m.get_option("ws_choice") >> 12) & 3
+    assert picked in (1, 3) and m.get_option("tuned_class") == 6 and m.get_option("last_sweep") == picked
+    assert m.get_option("tuned_nm_us") > 0 and m.get_option("tuned_leave_us") > 0
+    want = o.batch(q, qo, limit=10)
+    live = np.arange(10)[None, :] < want["counts"][:, None].astype(np.int64)
+    assert np.array_equal(counts, want["counts"])
+    assert np.array_equal(np.where(live[:, :, None], rows, 0), np.where(live[:, :, None], want["rows"], 0))
+    rows2, counts2 = m.find_batch_packed(q, qo, 10)            # the choice serves the class
+    assert m.get_option("last_sweep") == picked and np.array_equal(rows2, rows) and np.array_equal(counts2, counts)
+    q3, qo3 = W.queries(hay, off, 600, 72)                     # under 1 024 needles: nothing is measured
+    before = m.get_option("ws_choice")
+    m.find_batch_packed(q3, qo3, 10)
+    assert m.get_option("ws_choice") == before
+    m.close()
