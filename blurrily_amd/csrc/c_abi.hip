@@ -380,9 +380,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
     uint32_t ranges = 1;
     // Tasks aimed at: two per workgroup for a handful of needles, four from a hundred needles on
-    // (measured, tools/batch_sweep.py); from about one needle per workgroup whole needles win.
+    // (measured, tools/batch_sweep.py); from about one needle per FOUR workgroups whole needles win (through round 4:
+    // per workgroup -- the whole-needle sweeps have become faster since, the ranged one pays its learning sweep and
+    // merge: at Geonames scale 256 needles 503 -> 366 us, 512: 737 -> 617).
     const size_t target_tasks = (n <= 96 ? 2 : 4) * wgs;
-    if (limit <= 1024 && target_tasks / n >= 4 && ix.n_windows > 2) {
+    if (limit <= 1024 && n * 4 <= wgs && ix.n_windows > 2) {
       ranges = uint32_t(std::min<size_t>((ix.n_windows + 1) / 2, target_tasks / n));   // ranges are whole window pairs
       ranges = std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit));     // merge pool
     }
@@ -492,7 +494,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // (at the same mean_hit_slice one family of haystacks wins 1.4x with the window-major sweep
     // where another loses 0.7x; leaving slices out wins 14 % on a haystack four times Geonames scale, 3 % at
     // Geonames scale, and LOSES 9 % there on needles without a close match), so the choice is MEASURED: the first
-    // batch of a class -- limit up to / above 32, by batch size 1 024.. / 16 384.. / 65 536.. / 262 144.. -- on an image runs
+    // batch of a class -- limit up to / above 32, by batch size 129.. / 16 384.. / 65 536.. / 262 144.. -- on an image runs
     // every sweep it can take (they give the same rows; that one call waits for them), the plain sweep twice -- the
     // first run of all meets cold caches -- and the fastest serves the class until the image is rebuilt or an option
     // changes; a sweep other than the plain one has to win by 1.5 % (window-major: 5 %, it pays a launch per window).
@@ -519,11 +521,11 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       const double slice_factor = (n_cls < 65536 ? (limit > 32 ? 4.0 : 1.7) : (limit > 32 ? 1.7 : 1.0));
       const int static_choice = ws_possible && ix.mean_hit_slice >= slice_factor * double(m->ws_static_slice) ? 2
                                 : leave_possible && ix.n_windows >= m->nm_min_windows ? 3 : 1;
-      // (classes 6 and 7: batches of 1 024 .. 16 383 needles -- a server's coalesced FINDs; at Geonames scale leaving slices
+      // (classes 6 and 7: batches of 129 .. 16 383 needles -- a server's coalesced FINDs; at Geonames scale leaving slices
       // out wins there as it does on large batches: 0.9 -> 0.8 ms for 1 024 needles, 2.6 -> 2.1 for 4 096, 6.4 -> 5.4 for
       // 12 000, which the static rule -- from 256 windows on -- gave away through round 5's first half)
       const int cls = n_cls < 16384 ? (limit > 32 ? 7 : 6) : (limit > 32 ? 3 : 0) + (n_cls < 65536 ? 0 : n_cls < 262144 ? 1 : 2);
-      const bool tunable = m->ws_autotune && is_base && n_cls >= 1024 && (leave_possible || ws_possible);
+      const bool tunable = m->ws_autotune && is_base && n_cls >= 129 && (leave_possible || ws_possible);
       // what the class's last batch took, if it has finished (never waited for): slow against the measurement?
       if (tunable && !cb && m->watch_pending[cls] && hipEventQuery(m->watch_ev[cls][1]) == hipSuccess) {
         float ms = 0.f;

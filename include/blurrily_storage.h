@@ -128,7 +128,7 @@ int blurrily_storage_find_batch(trigram_map haystack, const char* packed,
  *   - the first call after a blurrily_storage_delete uploads the deleted ranks and
  *     sets their tombstone bits (a synchronous copy and a stream synchronise);
  *   - with "ws_autotune" 1 (the default), the FIRST batch of a class -- limit up
- *     to / above 32 x 1 024.. / 16 384.. / 65 536.. / 262 144.. needles -- on an image runs
+ *     to / above 32 x 129.. / 16 384.. / 65 536.. / 262 144.. needles -- on an image runs
  *     every sweep that can serve it and waits for them once, to note the fastest
  *     (blurrily_storage_tune does that ahead of time; "ws_autotune" 0 never does);
  *   - blurrily_storage_set_timing(1) and blurrily_storage_set_stats(1).
@@ -247,7 +247,7 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_min_windows"  (8)     fewest windows of an image it is taken on
  *   "ws_min_slice"    (1550)  least mean postings a needle trigram finds per window for the sweep to be possible on
  *                             an image at all (such an image carries bitmaps of its dense slices)
- *   "ws_autotune"     (1)     which sweep serves a class of batches (limit up to / above 32; 1 024.. / 16 384.. / 65 536.. /
+ *   "ws_autotune"     (1)     which sweep serves a class of batches (limit up to / above 32; 129.. / 16 384.. / 65 536.. /
  *                             262 144.. needles) is MEASURED: the first such batch on an image runs every sweep it can
  *                             take -- needle-major, window-major, needle-major with dense slices left out of the count
  *                             -- TWICE, the better run counting (same rows; that one call waits for them, see
@@ -261,7 +261,7 @@ int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_
  *   "ws_choice"       get: what has been measured (class c in bits 2c+1:2c: 0 not yet, 1 needle-major,
  *                             2 window-major, 3 needle-major with slices left out; classes 0..2: limits up to 32 by
  *                             batch size 16 384.. / 65 536.. / 262 144.., 3..5: the same for limits above 32, 6 / 7:
- *                             batches of 1 024 .. 16 383 needles, limits up to / above 32); set 0: forget it
+ *                             batches of 129 .. 16 383 needles, limits up to / above 32); set 0: forget it
  *   "tuned_class", "tuned_nm_us", "tuned_ws_us", "tuned_leave_us"   get: the class measured most recently (-1: none)
  *                             and what its three sweeps took, in microseconds (0: that sweep could not run)
  *   "last_sweep"      get: which sweep the last large batch took (1 / 2 / 3 as above, 4: the small-haystack sweep; 0: latency mode)

@@ -209,7 +209,7 @@ def test_a_bad_first_sample_of_the_measured_choice_is_corrected(geonames_full):
 
 
 def test_mid_size_batches_have_their_sweep_measured_too():
-    """Batches of 1 024 .. 16 383 needles -- a server's coalesced FINDs -- are a class of their own (6; 7 above limit 32)
+    """Batches of 129 .. 16 383 needles -- a server's coalesced FINDs -- are a class of their own (6; 7 above limit 32)
     whose first batch measures the sweeps like a large one's (c_abi.hip: run_find_on); smaller batches keep the static
     rule.  Same rows whatever is chosen."""
     hay, off = W.geonames(700000, 90000, 51)                   # 11 windows: the static rule alone would never leave a slice out
@@ -229,7 +229,7 @@ def test_mid_size_batches_have_their_sweep_measured_too():
     assert np.array_equal(np.where(live[:, :, None], rows, 0), np.where(live[:, :, None], want["rows"], 0))
     rows2, counts2 = m.find_batch_packed(q, qo, 10)            # the choice serves the class
     assert m.get_option("last_sweep") == picked and np.array_equal(rows2, rows) and np.array_equal(counts2, counts)
-    q3, qo3 = W.queries(hay, off, 600, 72)                     # under 1 024 needles: nothing is measured
+    q3, qo3 = W.queries(hay, off, 100, 72)                     # a hundred needles (latency mode): nothing is measured
     before = m.get_option("ws_choice")
     m.find_batch_packed(q3, qo3, 10)
     assert m.get_option("ws_choice") == before
