@@ -7,7 +7,9 @@ import workloads as W
 from blurrily_amd import RawMap
 hay, off = W.bench_haystack("words", 1.0)
 n = len(off) - 1
-m = RawMap(); m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32)); m.sync_device()
+m = RawMap()
+if os.environ.get('SMALL_MIN'): m.set_option('small_min_needles', int(os.environ['SMALL_MIN']))
+m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32)); m.sync_device()
 for batch in (int(x) for x in os.environ.get("BATCHES", "64,128,192,256,384,512,1024,2048,4096").split(",")):
     qq, qqo = W.queries(hay, off, batch, 9)
     t = []
