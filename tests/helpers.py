@@ -49,6 +49,7 @@ class Oracle:
     def __init__(self):
         self.L = self.lib()
         self.h = self.L.oracle_new()
+        self._gen = 0                                            # bumped by every mutation (batch_upto's kept answer)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -56,13 +57,16 @@ class Oracle:
             self.h = None
 
     def put(self, needle, ref, weight=0):
+        self._gen += 1
         return self.L.oracle_put(self.h, needle, ref, weight)
 
     def put_many(self, packed, offsets, refs=None):
+        self._gen += 1
         return self.L.oracle_put_many(self.h, packed.ctypes.data, offsets.ctypes.data,
                                       None if refs is None else refs.ctypes.data, len(offsets) - 1)
 
     def delete(self, ref):
+        self._gen += 1
         return self.L.oracle_delete(self.h, ref)
 
     def find(self, needle, limit=10):
@@ -101,6 +105,27 @@ class Oracle:
         self.L.oracle_batch(self.h, packed.ctypes.data, offsets.ctypes.data, ptr(idx_a), n, limit,
                             ptr(rows), ptr(counts), ptr(nb_a), ptr(nt_a), threads)
         return out
+
+    def batch_upto(self, packed, offsets, limit, upto, spot=96):
+        """``batch(packed, offsets, limit=limit)`` for a test that asks the SAME needles of the SAME oracle at several
+        limits: the answer at ``limit`` is the head of the answer at ``upto`` >= limit (storage.c:568-573 truncates one
+        total order -- matches, weight, reference -- to the limit), so the oracle runs once at ``upto`` and later
+        limits are cut from it.  The first ``spot`` needles are asked at ``limit`` itself every time and must agree
+        with the cut.  The kept answer is dropped when the oracle or the batch changes (caller's arrays are held)."""
+        assert limit <= upto
+        key = (id(packed), id(offsets), upto, self._gen)
+        if getattr(self, "_upto_key", None) != key:
+            self._upto_key, self._upto_hold = key, (packed, offsets)
+            self._upto_ans = self.batch(packed, offsets, limit=upto)
+        rows = self._upto_ans["rows"][:, :max(limit, 1)].copy()
+        counts = np.minimum(self._upto_ans["counts"], limit).astype(np.uint32)
+        n_spot = min(spot, len(offsets) - 1)
+        if n_spot and limit != upto:
+            d = self.batch(packed, offsets, idx=np.arange(n_spot, dtype=np.uint32), limit=limit)
+            assert np.array_equal(d["counts"], counts[:n_spot])
+            live = np.arange(max(limit, 1))[None, :] < counts[:n_spot, None].astype(np.int64)
+            assert np.array_equal(np.where(live[:, :, None], d["rows"], 0), np.where(live[:, :, None], rows[:n_spot], 0))
+        return {"rows": rows, "counts": counts}
 
     @classmethod
     def tokenise(cls, needle):

@@ -149,3 +149,40 @@ def test_batch_driver_equals_single_calls():
             assert int(got["ntri"][k]) == len(Oracle.tokenise(nd))
     every = o.batch(q, qo, find=False, nb=True)
     assert [int(v) for v in every["nb"]] == [o.nb_entries(nd) for nd in needles]
+
+
+@pytest.mark.parametrize("kind", ["geonames", "skewed"])
+def test_an_answer_at_a_limit_is_the_head_of_the_answer_at_a_larger_one(kind):
+    """helpers.Oracle.batch_upto (the GPU tests that ask one batch at several limits run the oracle once, at the
+    largest): storage.c:568-573 truncates ONE total order to the limit, so every limit's rows are the head of a larger
+    limit's -- held here on every needle, incl. the skewed haystack's floods of (matches, weight) ties, and against
+    the live reference where it is built.  A mutation drops the kept answer."""
+    hay, off = W.geonames(30000, 4000, 17) if kind == "geonames" else W.skewed(30000, 18)
+    o = Oracle()
+    o.put_many(hay, off)
+    q, qo = W.queries(hay, off, 400, 19)
+    for limit in (149, 1, 3, 10, 64, 100):
+        direct = o.batch(q, qo, limit=limit)
+        cut = o.batch_upto(q, qo, limit, 149, spot=0)
+        assert np.array_equal(direct["counts"], cut["counts"])
+        live = np.arange(limit)[None, :] < direct["counts"][:, None].astype(np.int64)
+        assert np.array_equal(np.where(live[:, :, None], direct["rows"], 0), np.where(live[:, :, None], cut["rows"], 0))
+    kept = o._upto_key
+    o.delete(int(o.batch(q, qo, idx=np.arange(1, dtype=np.uint32), limit=1)["rows"][0, 0, 0]) or 1)
+    after = o.batch_upto(q, qo, 10, 149)                        # (asked again: the first needle's best reference is gone)
+    assert o._upto_key != kept
+    assert np.array_equal(after["counts"], o.batch(q, qo, limit=10)["counts"])
+    if Reference.available():
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "m.trigrams")
+            m = RawMap()
+            m.put_many_packed(hay, off, np.arange(1, len(off), dtype=np.uint32))
+            m.save(path)
+            ref = Reference(path)
+            o2 = Oracle()                                       # (unmutated)
+            o2.put_many(hay, off)
+            big = o2.batch(q, qo, limit=149)
+            for k, nd in enumerate(W.unpack(q, qo)[:60]):
+                for limit in (1, 10, 64):
+                    assert ref.find(nd, limit) == big["rows"][k, :min(int(big["counts"][k]), limit)].tolist()
+            ref.close()
