@@ -48,7 +48,8 @@ Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carr
                  benchmark (doc/bench.numbers: single-find latency on six dataset sizes, eight fixed
                  needles, limit 10) -- p50 of blurrily_storage_find (one launch, no copy) beside the
                  compiled reference on one core of this box, all 48 answers compared row for row.
-  p50_query_us   the other half of BASELINE.json's metric: host clock around blurrily_storage_find.
+  p50_query_us   the other half of BASELINE.json's metric: host clock around blurrily_storage_find
+                 (`latency_probes` single finds, one after the other); `p99_query_us`: the same probes' tail.
 
 `roofline.bound` says what the profiles support: "hbm" only where the image exceeds the L2 and the rate
 reaches 0.6 of the peak; otherwise "latency chain" (the step's dependent LDS round trips and barriers,
@@ -583,7 +584,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     out, parity_ok = None, True
     if rank == 0:
         # p50 single-needle latency through blurrily_storage_find (host buffers, sync per call)
-        p50_us, host_rate = None, None
+        p50_us, p99_us, host_rate = None, None, None
         m.set_timing(False)          # (the HIP-event bracket of the timed steps is not part of a plain find)
         if latency_probes:
             raw = W.unpack(qp, qo[:latency_probes + 1])
@@ -594,6 +595,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 lib.blurrily_storage_find(m.handle, nd, limit, rows)
                 lat.append(time.perf_counter() - t)
             p50_us = float(np.median(lat) * 1e6) if lat else None
+            p99_us = float(np.percentile(lat, 99) * 1e6) if lat else None     # (a server's tail: same probes, same clock)
             # the same batch through the host-buffer entry point: H2D of the needles and D2H of the
             # result rows included (reported beside `value`, never as `value`).  The caller's buffers are
             # allocated and touched once, as a host program calling blurrily_storage_find_batch in a loop
@@ -631,6 +633,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                                        f"rows sent into device 0's buffers by peer copies" if devices > 1 else f"query-shard x{world}"),
                        "scale": args.scale},
             "p50_query_us": p50_us,
+            "p99_query_us": p99_us,
+            "latency_probes": int(latency_probes),
             "host_buffer_queries_per_sec": host_rate,
             "matched_entries_per_sec": total_entries * steps / elapsed,
             "entries_per_query": sum_nb / n_q,
@@ -814,7 +818,7 @@ def main():
                 line, ok_x = run_workload(name, args, max(3, min(args.steps, 10)), 1, rank, local_rank, world, dist,
                                           min(budget, 4.0), min(args.latency_probes, 50))
                 ok = ok and ok_x
-                extra[name] = {k: line[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "p50_query_us",
+                extra[name] = {k: line[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "p50_query_us", "p99_query_us",
                                                     "matched_entries_per_sec", "entries_per_query", "kernel_ms", "sweep_retunes",
                                                     "roofline", "cpu_baseline", "parity_checked") if k in line}
             except Exception as e:                   # recorded, and the run exits 1
