@@ -590,6 +590,8 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             raw = W.unpack(qp, qo[:latency_probes + 1])
             rows = (_native.TrigramMatch * limit)()
             lat = []
+            for nd in raw[:3]:                       # (the first single find on a map sets up its stream and its pinned page)
+                lib.blurrily_storage_find(m.handle, nd, limit, rows)
             for nd in raw:
                 t = time.perf_counter()
                 lib.blurrily_storage_find(m.handle, nd, limit, rows)
