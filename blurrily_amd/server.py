@@ -169,7 +169,12 @@ class Server:
                     n += len(item[0])
                 # everything that touches a map runs on the one worker thread, in arrival order
                 lines = [line for chunk, _ in work for line in chunk]
-                results = await loop.run_in_executor(self._gpu, self._run, lines)
+                try:
+                    results = await loop.run_in_executor(self._gpu, self._run, lines)
+                except asyncio.CancelledError:
+                    raise
+                except Exception as e:                               # (_run answers per line; whatever still escapes must
+                    results = [reply_error(str(e))] * len(lines)     #  not end the dispatcher and leave every client waiting)
                 at = 0
                 for chunk, fut in work:
                     if not fut.done():

@@ -263,3 +263,39 @@ def test_server_refuses_an_endless_line(running_server):
     f = s.makefile("rb")
     assert f.readline() == b"ERROR\tline too long\n"
     assert f.readline() == b""                                  # and the connection is closed
+
+
+def test_dispatcher_outlives_an_exception_that_escapes_a_batch(tmp_path):
+    """Whatever escapes Server._run (it answers per line, so nothing should) becomes an ERROR reply for the lines of
+    that batch; the dispatcher goes on and the next command is served -- a dead dispatcher would leave every client
+    waiting on an open connection (the reference's reactor would have died: server.rb:40-46 has no rescue)."""
+    import asyncio
+    from blurrily_amd.server import Server
+
+    async def scenario():
+        srv = Server("127.0.0.1", 0, str(tmp_path))
+        ready = asyncio.Event()
+        task = asyncio.ensure_future(srv.serve(ready))
+        await ready.wait()
+        real_run, calls = srv._run, []
+
+        def flaky(lines):
+            calls.append(list(lines))
+            if len(calls) == 1:
+                raise RuntimeError("boom")
+            return real_run(lines)
+        srv._run = flaky
+        reader, writer = await asyncio.open_connection("127.0.0.1", srv.port)
+        writer.write(b"PUT\twords\tmerveilleux\t1\n")
+        await writer.drain()
+        first = await asyncio.wait_for(reader.readline(), 10)
+        writer.write(b"PUT\twords\tmerveille\t2\n")
+        await writer.drain()
+        second = await asyncio.wait_for(reader.readline(), 10)
+        writer.close()
+        srv.stop()
+        await asyncio.wait_for(task, 30)
+        return first, second
+
+    first, second = asyncio.run(scenario())
+    assert first == b"ERROR\tboom\n" and second == b"OK\n"
