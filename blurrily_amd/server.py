@@ -12,6 +12,7 @@ import argparse
 import asyncio
 import os
 import signal
+from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 
 from .command_processor import (COMMANDS, CommandProcessor, Find, ProtocolError, reply_error, reply_ok, reply_rows,
@@ -33,7 +34,7 @@ class Server:
         self._processor = CommandProcessor(self._map_group)
         self._max_batch = max_batch if coalesce else 1
         self._save_interval = save_interval
-        self._pending = []                                           # (line, future) in arrival order
+        self._pending = deque()                                      # (lines, future) in arrival order
         self._wake = None
         self._gpu = ThreadPoolExecutor(max_workers=1)                # one batch at a time, off the reactor
         self._server = None
@@ -164,7 +165,7 @@ class Server:
             while self._pending:
                 work, n = [], 0
                 while self._pending and (not work or n + len(self._pending[0][0]) <= self._max_batch):
-                    item = self._pending.pop(0)
+                    item = self._pending.popleft()
                     work.append(item)
                     n += len(item[0])
                 # everything that touches a map runs on the one worker thread, in arrival order
