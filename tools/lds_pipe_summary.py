@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""LDS-pipe occupancy of the batch kernels from the rocprofv3 --pmc passes tools/lds_pipe.sh leaves in
+<dir>/pmc_{idx,inst,mix}_<workload>/ (sqlite output).
+
+Per workload, for the ONE kernel the timed step spends its time in (the counted build's launch -- namespace
+blurrily::counted -- left out): the SQ counters summed over its dispatches, and
+
+  lds_busy_frac      SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES   -- the share of a busy CU's cycles in which its LDS array works
+                     (MI355X_MICROARCH.md: SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones)
+  conflict_frac      SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  wait_lds_frac      SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES       -- the share of wave-cycles spent waiting on an LDS instruction
+
+Prints one JSON object stamped with bench.py's kernel_source_hash (what the bench line checks freshness against)."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+KERNEL = {"geonames": "find_kernel<unsigned char, 1024, false, true, true>", "words": "find_small_kernel"}
+
+
+def counters(dirpath, kernel):
+    dbs = glob.glob(os.path.join(dirpath, "**", "*.db"), recursive=True)
+    if not dbs:
+        return {}
+    c = sqlite3.connect(dbs[0])
+    rows = c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id), sum(duration) "
+                     "from counters_collection group by kernel_name, counter_name").fetchall()
+    out = {}
+    for k, n, v, disp, dur in rows:
+        if kernel not in k or "blurrily::counted::" in k:
+            continue
+        out[n] = out.get(n, 0.0) + v
+        out["_dispatches"] = disp
+    return out
+
+
+def main():
+    base = sys.argv[1]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = {"_how": " ".join(__doc__.split("\n\n")[1].split()), "kernel_source_hash": bench.kernel_source_hash(),
+           "commit": os.environ.get("PROFILE_COMMIT")}
+    for wl, kernel in KERNEL.items():
+        d = {"kernel": kernel}
+        for sub in ("idx", "inst", "mix"):
+            d.update(counters(os.path.join(base, f"pmc_{sub}_{wl}"), kernel))
+        g = d.get
+        if g("SQ_LDS_IDX_ACTIVE") and g("SQ_BUSY_CU_CYCLES"):
+            d["lds_busy_frac"] = g("SQ_LDS_IDX_ACTIVE") / g("SQ_BUSY_CU_CYCLES")
+            d["conflict_frac"] = g("SQ_LDS_BANK_CONFLICT", 0.0) / g("SQ_LDS_IDX_ACTIVE")
+        if g("SQ_WAIT_INST_LDS") and g("SQ_WAVE_CYCLES"):
+            d["wait_lds_frac"] = g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")
+        if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"):
+            d["wait_any_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+        try:
+            line = json.loads(open(os.path.join(base, f"pmc_idx_{wl}", "bench.json")).read().strip().splitlines()[-1])
+            d["kernel_ms_under_pmc"] = line.get("kernel_ms")
+            d["sweep"] = line.get("roofline", {}).get("sweep")
+        except Exception:
+            pass
+        out[wl] = d
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
