@@ -555,6 +555,29 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
         except Exception as e:
             pmc = {"error": str(e)}
 
+    # ... and how busy the LDS array was under this workload's dominant kernel (SQ_LDS_IDX_ACTIVE over SQ_BUSY_CU_CYCLES,
+    # tools/lds_pipe.sh: a separate run of this command under rocprofv3 --pmc, stamped like the traffic figure): the
+    # counters, their scan's reads and clears and the bank-conflict replays all pass through it -- the one resource the
+    # workgroups of a CU share, and the roof `lds.frac` (atomic lanes alone) understates
+    lds_pipe = None
+    lpath = os.path.join(ROOT, "profiles", "lds_pipe_latest.json")
+    if os.path.exists(lpath) and args.scale == 1.0:
+        try:
+            prof = json.load(open(lpath))
+            if prof.get(name, {}).get("lds_busy_frac") is not None:
+                at, now = prof.get("kernel_source_hash"), kernel_source_hash()
+                lp = prof[name]
+                lds_pipe = {"busy_frac": lp["lds_busy_frac"], "bank_conflict_share": lp.get("conflict_frac"),
+                            "wave_cycles_waiting_on_lds": lp.get("wait_lds_frac"), "kernel": lp.get("kernel"),
+                            "profiled_at_commit": prof.get("commit"), "profiled_at_source_hash": at, "stale": at != now,
+                            "source": "profiles/lds_pipe_latest.json: SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES of the kernel over one "
+                                      "timed step, rocprofv3 --pmc, separate run (tools/lds_pipe.sh)"}
+                if lds_pipe["stale"]:
+                    log(f"WARNING: profiles/lds_pipe_latest.json was profiled at kernel sources {at}, this run is {now}: "
+                        f"the LDS-pipe figure of '{name}' is STALE (re-run tools/lds_pipe.sh)")
+        except Exception as e:
+            lds_pipe = {"error": str(e)}
+
     totals = torch.tensor([float(sum_nb), k_ms, float(np.mean(gather_ms)) if gather_ms else 0.0],
                           dtype=torch.float64, device=coll_dev)
     per_rank = None
@@ -702,6 +725,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 "postings_read_fraction": st["posting_entries"] / max(1, sum_nb),
                 "lds": {"atomic_lanes_per_launch": st["posting_entries"], "atomic_lanes_per_sec": lds_lanes,
                         "peak_lanes_per_sec": LDS_ATOMIC_PEAK_LANES, "frac": lds_lanes / LDS_ATOMIC_PEAK_LANES},
+                "lds_pipe": lds_pipe,
                 "counters": st,
                 "counted_launch_rows_equal_timed": stats_rows_equal,
                 "resident_index_bytes": int(info["device_bytes"])},

@@ -9,6 +9,7 @@ blurrily::counted -- left out): the SQ counters summed over its dispatches, and
                      (MI355X_MICROARCH.md: SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones)
   conflict_frac      SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
   wait_lds_frac      SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES       -- the share of wave-cycles spent waiting on an LDS instruction
+  valu_busy_frac     SQ_ACTIVE_INST_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES) -- the share of the VALU issue slots taken
 
 Prints one JSON object stamped with bench.py's kernel_source_hash (what the bench line checks freshness against)."""
 import glob
@@ -17,7 +18,8 @@ import os
 import sqlite3
 import sys
 
-KERNEL = {"geonames": "find_kernel<unsigned char, 1024, false, true, true>", "words": "find_small_kernel"}
+LEAVE = "find_kernel<unsigned char, 1024, false, true, true>"
+KERNEL = {"geonames": LEAVE, "words": "find_small_kernel", "geonames_x4": LEAVE, "skewed": LEAVE}
 
 
 def counters(dirpath, kernel):
@@ -44,12 +46,18 @@ def main():
            "commit": os.environ.get("PROFILE_COMMIT")}
     for wl, kernel in KERNEL.items():
         d = {"kernel": kernel}
-        for sub in ("idx", "inst", "mix"):
+        for sub in ("idx", "inst", "mix", "valu"):
             d.update(counters(os.path.join(base, f"pmc_{sub}_{wl}"), kernel))
         g = d.get
         if g("SQ_LDS_IDX_ACTIVE") and g("SQ_BUSY_CU_CYCLES"):
             d["lds_busy_frac"] = g("SQ_LDS_IDX_ACTIVE") / g("SQ_BUSY_CU_CYCLES")
             d["conflict_frac"] = g("SQ_LDS_BANK_CONFLICT", 0.0) / g("SQ_LDS_IDX_ACTIVE")
+        # a wave64 VALU instruction holds its SIMD for one quad-cycle (SQ_ACTIVE_INST_VALU counts those; it equals
+        # SQ_INSTS_VALU to within a percent on these kernels), a CU has four SIMDs: busy share of the VALU issue slots
+        valu_q = g("SQ_ACTIVE_INST_VALU") or g("SQ_INSTS_VALU")
+        if valu_q and g("SQ_BUSY_CU_CYCLES"):
+            d["valu_busy_frac"] = valu_q * 4.0 / (4.0 * g("SQ_BUSY_CU_CYCLES"))
+            d["valu_busy_from"] = "SQ_ACTIVE_INST_VALU" if g("SQ_ACTIVE_INST_VALU") else "SQ_INSTS_VALU"
         if g("SQ_WAIT_INST_LDS") and g("SQ_WAVE_CYCLES"):
             d["wait_lds_frac"] = g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")
         if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"):
