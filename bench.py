@@ -569,6 +569,10 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 lp = prof[name]
                 lds_pipe = {"busy_frac": lp["lds_busy_frac"], "bank_conflict_share": lp.get("conflict_frac"),
                             "wave_cycles_waiting_on_lds": lp.get("wait_lds_frac"), "kernel": lp.get("kernel"),
+                            # the VALU's issue slots beside it (a wave64 instruction holds one of a CU's four SIMDs for
+                            # four cycles): what the step's ~4 000 VALU instructions take of the CU
+                            "valu_busy_frac": lp.get("valu_busy_frac"),
+                            "wave_cycles_waiting": lp.get("wait_any_frac"),
                             "profiled_at_commit": prof.get("commit"), "profiled_at_source_hash": at, "stale": at != now,
                             "source": "profiles/lds_pipe_latest.json: SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES of the kernel over one "
                                       "timed step, rocprofv3 --pmc, separate run (tools/lds_pipe.sh)"}
@@ -673,7 +677,13 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # barrier; profiles/r04_step_timeline.md) whose time does not follow the bytes -- `nearest_roof` then
                 # names the memory level the image lives in, and achieved / peak / frac stay that of the HBM roof the
                 # path is held against (an image in L2: see `l2`)
+                # ... unless the stamped SQ counters of this workload (profiles/lds_pipe_latest.json, `lds_pipe` below) show
+                # a pipe of the CU at 0.6 or more of its issue slots: then that pipe is what more chains per CU would run into
                 "bound": ("hbm" if info["device_bytes"] > L2_AGGREGATE_BYTES and req_gbs / HBM_PEAK_GBS >= 0.6
+                          else "valu issue" if lds_pipe and not lds_pipe.get("stale", True) and
+                          (lds_pipe.get("valu_busy_frac") or 0.0) >= 0.6 and
+                          (lds_pipe.get("valu_busy_frac") or 0.0) >= (lds_pipe.get("busy_frac") or 0.0)
+                          else "lds pipe" if lds_pipe and not lds_pipe.get("stale", True) and (lds_pipe.get("busy_frac") or 0.0) >= 0.6
                           else "latency chain"),
                 "nearest_roof": "l2" if info["device_bytes"] <= L2_AGGREGATE_BYTES else "hbm",
                 "achieved": req_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
