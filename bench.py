@@ -52,8 +52,12 @@ Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carr
                  (`latency_probes` single finds, one after the other); `p99_query_us`: the same probes' tail.
 
 `roofline.bound` says what the profiles support: "hbm" only where the image exceeds the L2 and the rate
-reaches 0.6 of the peak; otherwise "latency chain" (the step's dependent LDS round trips and barriers,
-DESIGN.md section 5) with `nearest_roof` and, for an image that lives in L2, the L2 fraction beside it.
+reaches 0.6 of the peak; "valu issue" / "lds pipe" where the workload's stamped SQ counters (`roofline.lds_pipe`,
+from profiles/lds_pipe_latest.json -- tools/lds_pipe.sh, a separate rocprofv3 --pmc run -- at these kernel sources)
+show that pipe of the CU at 0.6 or more of its slots (round 5: the VALU's issue slots are 0.7-0.8 busy under every
+batch kernel, the LDS array 0.3-0.5: DESIGN.md section 5d); otherwise "latency chain" (the step's dependent LDS round
+trips and barriers) with `nearest_roof` and, for an image that lives in L2, the L2 fraction beside it.  achieved /
+peak / frac stay those of the HBM roof whatever `bound` says.
 `--scaling strong` (N > 1) splits configs[3]'s literal 8 M-needle batch over the ranks instead of giving
 each its own 1 M; `n_gpus` counts DISTINCT physical devices (`distinct_devices`, by UUID / PCI bus id).
 
@@ -116,6 +120,19 @@ def code_only(text):
         else:
             out.append(c); i += 1
     return " ".join("".join(out).split())
+
+
+def bound_label(device_bytes, hbm_frac, pipes):
+    """roofline.bound: what the profiles support.  "hbm" where the requested bytes are memory-side bytes and reach 0.6 of
+    the peak; "valu issue" / "lds pipe" where the workload's stamped SQ counters (profiles/lds_pipe_latest.json, fresh)
+    show that pipe of the CU at 0.6 or more of its slots -- the fuller of the two; else "latency chain"."""
+    if device_bytes > L2_AGGREGATE_BYTES and hbm_frac >= 0.6:
+        return "hbm"
+    if pipes and not pipes.get("stale", True) and "error" not in pipes:
+        valu, lds = pipes.get("valu_busy_frac") or 0.0, pipes.get("busy_frac") or 0.0
+        if max(valu, lds) >= 0.6:
+            return "valu issue" if valu >= lds else "lds pipe"
+    return "latency chain"
 
 
 def kernel_source_hash():
@@ -679,12 +696,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # path is held against (an image in L2: see `l2`)
                 # ... unless the stamped SQ counters of this workload (profiles/lds_pipe_latest.json, `lds_pipe` below) show
                 # a pipe of the CU at 0.6 or more of its issue slots: then that pipe is what more chains per CU would run into
-                "bound": ("hbm" if info["device_bytes"] > L2_AGGREGATE_BYTES and req_gbs / HBM_PEAK_GBS >= 0.6
-                          else "valu issue" if lds_pipe and not lds_pipe.get("stale", True) and
-                          (lds_pipe.get("valu_busy_frac") or 0.0) >= 0.6 and
-                          (lds_pipe.get("valu_busy_frac") or 0.0) >= (lds_pipe.get("busy_frac") or 0.0)
-                          else "lds pipe" if lds_pipe and not lds_pipe.get("stale", True) and (lds_pipe.get("busy_frac") or 0.0) >= 0.6
-                          else "latency chain"),
+                "bound": bound_label(info["device_bytes"], req_gbs / HBM_PEAK_GBS, lds_pipe),
                 "nearest_roof": "l2" if info["device_bytes"] <= L2_AGGREGATE_BYTES else "hbm",
                 "achieved": req_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": req_gbs / HBM_PEAK_GBS,
@@ -719,8 +731,10 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                 # a chain of steps -- count, barrier, scan, barrier -- of ~4 us each whatever they read, two (small images:
                 # four) chains per CU because of the counters' LDS; the bytes are what the steps move, not what binds them
                 "bound_note": "hbm is the roofline this integer gather/count path is held against (frac); where `bound` says "
-                              "latency chain the kernel is bound by its per-step chain (barriers, LDS round trips, one global "
-                              "latency), see DESIGN.md section 5 and profiles/r04_step_timeline.md",
+                              "valu issue the CU's VALU issue slots are the fullest pipe (lds_pipe.valu_busy_frac, SQ counters of "
+                              "one timed step: DESIGN.md section 5d); where it says latency chain no counter profile of this "
+                              "workload at these sources supports more than the per-step chain (barriers, LDS round trips, one "
+                              "global latency: profiles/r04_step_timeline.md)",
                 "kernel_source_hash": kernel_source_hash(),
                 "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
                            else "find_kernel<uint8_t,1024,false,true,true> (manager + workers; slices left out, settled by bitmap)"
