@@ -10,6 +10,7 @@ blurrily::counted -- left out): the SQ counters summed over its dispatches, and
   conflict_frac      SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
   wait_lds_frac      SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES       -- the share of wave-cycles spent waiting on an LDS instruction
   valu_busy_frac     SQ_ACTIVE_INST_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES) -- the share of the VALU issue slots taken
+                     (rocprofiler's derived VALUBusy = 100*SQ_ACTIVE_INST_VALU*4/SIMD_NUM/GRBM_GUI_ACTIVE, over busy CU cycles)
 
 Prints one JSON object stamped with bench.py's kernel_source_hash (what the bench line checks freshness against)."""
 import glob
