@@ -11,7 +11,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for wl in "geonames:3" "words:4" "geonames_x4:3" "skewed:3"; do
+for wl in "geonames:3" "words:4" "geonames_x4:3" "skewed:3" "geonames_miss:3"; do
   name=${wl%%:*}; fs=${wl#*:}
   for pass in "idx:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES" "inst:SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "mix:SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY" "valu:SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY"; do
     p=${pass%%:*}; ctrs=${pass#*:}

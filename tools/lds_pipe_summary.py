@@ -20,7 +20,7 @@ import sqlite3
 import sys
 
 LEAVE = "find_kernel<unsigned char, 1024, false, true, true>"
-KERNEL = {"geonames": LEAVE, "words": "find_small_kernel", "geonames_x4": LEAVE, "skewed": LEAVE}
+KERNEL = {"geonames": LEAVE, "words": "find_small_kernel", "geonames_x4": LEAVE, "skewed": LEAVE, "geonames_miss": LEAVE}
 
 
 def counters(dirpath, kernel):
