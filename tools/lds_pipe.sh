@@ -13,7 +13,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for wl in "geonames:3" "words:4" "geonames_x4:3" "skewed:3" "geonames_miss:3"; do
   name=${wl%%:*}; fs=${wl#*:}
-  for pass in "idx:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES" "inst:SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "mix:SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY" "valu:SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY"; do
+  for pass in "idx:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES" "inst:SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "mix:SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY" "valu:SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "salu:SQ_INST_CYCLES_SALU"; do
     p=${pass%%:*}; ctrs=${pass#*:}
     d=$out/pmc_${p}_$name
     mkdir -p $d

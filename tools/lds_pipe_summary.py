@@ -47,7 +47,7 @@ def main():
            "commit": os.environ.get("PROFILE_COMMIT")}
     for wl, kernel in KERNEL.items():
         d = {"kernel": kernel}
-        for sub in ("idx", "inst", "mix", "valu"):
+        for sub in ("idx", "inst", "mix", "valu", "salu"):
             d.update(counters(os.path.join(base, f"pmc_{sub}_{wl}"), kernel))
         g = d.get
         if g("SQ_LDS_IDX_ACTIVE") and g("SQ_BUSY_CU_CYCLES"):
@@ -59,6 +59,8 @@ def main():
         if valu_q and g("SQ_BUSY_CU_CYCLES"):
             d["valu_busy_frac"] = valu_q * 4.0 / (4.0 * g("SQ_BUSY_CU_CYCLES"))
             d["valu_busy_from"] = "SQ_ACTIVE_INST_VALU" if g("SQ_ACTIVE_INST_VALU") else "SQ_INSTS_VALU"
+        if g("SQ_INST_CYCLES_SALU") and g("SQ_BUSY_CU_CYCLES"):     # (rocprofiler's SALUBusy, the same way)
+            d["salu_busy_frac"] = g("SQ_INST_CYCLES_SALU") * 4.0 / (4.0 * g("SQ_BUSY_CU_CYCLES"))
         if g("SQ_WAIT_INST_LDS") and g("SQ_WAVE_CYCLES"):
             d["wait_lds_frac"] = g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")
         if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"):
