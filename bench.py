@@ -588,7 +588,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                             "wave_cycles_waiting_on_lds": lp.get("wait_lds_frac"), "kernel": lp.get("kernel"),
                             # the VALU's issue slots beside it (a wave64 instruction holds one of a CU's four SIMDs for
                             # four cycles): what the step's ~4 000 VALU instructions take of the CU
-                            "valu_busy_frac": lp.get("valu_busy_frac"),
+                            "valu_busy_frac": lp.get("valu_busy_frac"), "salu_busy_frac": lp.get("salu_busy_frac"),
                             "wave_cycles_waiting": lp.get("wait_any_frac"),
                             "profiled_at_commit": prof.get("commit"), "profiled_at_source_hash": at, "stale": at != now,
                             "source": "profiles/lds_pipe_latest.json: SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES of the kernel over one "
