@@ -12,7 +12,10 @@ per-rank result blocks are collected on rank 0 by ONE RCCL gather per step insid
 issued asynchronously, so that it travels over xGMI while the next step is searched into a second
 block; the region ends only when every gather has arrived.
 
-Rank 0 prints ONE JSON line; `value` is whole-job needles/s.  The same line carries
+Rank 0 prints ONE SHORT JSON line (compact_line: numbers and short tokens only, at most 6 000 bytes -- what the driver
+parses; tests/test_bench_line.py) and writes the whole record -- every field described below, notes, sources, counters,
+per-sweep measurements -- to bench_detail.json beside this script (`--detail PATH`; the path goes to stderr and into the
+line's `detail`).  `value` is whole-job needles/s.  The record carries, and the line summarises,
 
   roofline       the position of the dominant kernel against the HBM roofline, from PHYSICAL
                  bytes measured IN THIS RUN: what the kernels requested of the memory system in one
@@ -160,6 +163,112 @@ LDS_ATOMIC_PEAK_LANES = 9.34e12
 
 EXTRA_CONFIGS = ("words", "skewed", "geonames_x4", "geonames_miss")
 
+# ---- the line the driver reads ------------------------------------------------------------------------------------
+# Rank 0 prints ONE short JSON line: numbers and short tokens only (round 5's 24 kB line, prose included, was more than the
+# driver parsed).  Everything else -- notes, sources, counters, per-sweep measurements -- goes to bench_detail.json beside
+# this script (path on stderr), and the copies the judge reads to profiles/.
+LINE_MAX_BYTES = 6000
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+
+
+def _r(x, digits=4):
+    """a float to `digits` significant digits (ints, None and strings pass through)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(d, keys, digits=4):
+    return {k: _r(d[k], digits) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_roofline(rf):
+    if not isinstance(rf, dict):
+        return None
+    out = _pick(rf, ("bound", "nearest_roof", "achieved", "peak", "unit", "frac", "traffic"))
+    pmc = rf.get("pmc")
+    out["pmc"] = _pick(pmc, ("bytes_per_step", "frac", "stale")) if isinstance(pmc, dict) and "error" not in pmc else None
+    lp = rf.get("lds_pipe") if isinstance(rf.get("lds_pipe"), dict) else {}
+    out["valu_busy_frac"] = _r(lp.get("valu_busy_frac"))
+    out["salu_busy_frac"] = _r(lp.get("salu_busy_frac"))
+    out["lds_busy_frac"] = _r(lp.get("busy_frac"))
+    out["pipes_stale"] = lp.get("stale") if lp else None
+    out["algorithmic_ratio"] = _r(rf.get("algorithmic_ratio"))
+    out["postings_read_fraction"] = _r(rf.get("postings_read_fraction"))
+    out["kernel"] = rf.get("kernel")
+    out["kernel_ms"] = _r(rf.get("kernel_ms"))
+    return out
+
+
+def compact_cpu_baseline(cb):
+    if not isinstance(cb, dict):
+        return None
+    if "error" in cb:
+        return {"error": str(cb["error"])[:120]}
+    out = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_query", "parity_checked", "parity_mismatches"))
+    out["sample"] = f"first {cb.get('n_timed', '?')} needles of the step batch, 1 thread"
+    if isinstance(cb.get("all_cores"), dict) and "value" in cb["all_cores"]:
+        out["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+    return out
+
+
+def compact_extra(name, x):
+    if not isinstance(x, dict):
+        return None
+    if "error" in x:
+        return {"error": str(x["error"])[:120]}
+    if name == "published_curve":
+        pts = x.get("points", [])
+        return {"records": [p_["records"] for p_ in pts], "gpu_p50_us": [_r(p_["gpu_p50_us"], 3) for p_ in pts],
+                "ref_ms": [_r(p_.get("ref_ms"), 3) for p_ in pts], "published_linux64_i7_ms": x.get("published_linux64_i7_ms"),
+                "parity_checked": sum(p_.get("parity", {}).get("checked", 0) for p_ in pts),
+                "parity_mismatches": sum(p_.get("parity", {}).get("mismatches", 0) for p_ in pts)}
+    if name == "mid_batch":
+        return {k: _r(v, 3) for k, v in x.items()}
+    if x.get("present") is False:
+        return {"present": False}
+    rf, cb = x.get("roofline") or {}, x.get("cpu_baseline") or {}
+    pmc = rf.get("pmc") if isinstance(rf.get("pmc"), dict) else {}
+    out = _pick(x, ("value", "ms_per_step", "kernel_ms", "p50_query_us", "p99_query_us"))
+    out.update(frac=_r(rf.get("frac")), pmc_frac=_r(pmc.get("frac")), bound=rf.get("bound"), kernel=rf.get("kernel"),
+               cpu_value=_r(cb.get("value")), parity_checked=cb.get("parity_checked"),
+               parity_mismatches=cb.get("parity_mismatches"))
+    if "error" in cb:
+        out["cpu_error"] = str(cb["error"])[:80]
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The driver's line from a workload's full record (run_workload's dict, extra_configs included)."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "replicas", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "vs_baseline", "dtype", "data"))
+    out["config"] = _pick(full.get("config", {}), ("workload", "haystack_strings", "haystack_entries", "needles_per_gpu",
+                                                   "limit", "index_replicated", "parallelism", "scale"))
+    out.update(_pick(full, ("p50_query_us", "p99_query_us", "matched_entries_per_sec", "entries_per_query", "kernel_ms",
+                            "host_buffer_queries_per_sec", "sweep_retunes", "retimed", "first_ms_per_step")))
+    out["roofline"] = compact_roofline(full.get("roofline"))
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = compact_cpu_baseline(full["cpu_baseline"])
+    if "extra_configs" in full:
+        out["extra_configs"] = {k: compact_extra(k, v) for k, v in full["extra_configs"].items()}
+        if "geonames_x4" in full["extra_configs"]:
+            out["roofline"]["hbm_point"] = "geonames_x4"    # the one image several times the Infinity Cache: HBM bytes
+    if "collective" in full:
+        c = full["collective"]
+        out["collective"] = _pick(c, ("backend", "world", "rccl_version", "distinct_devices"))
+        out.update(_pick(full, ("gather_ms", "gather_bytes_per_rank", "gather_checked")))
+        out["per_rank_kernel_ms"] = [_r(v, 4) for v in full.get("per_rank", {}).get("kernel_ms", [])]
+    if "in_process" in full:
+        out["in_process"] = _pick(full["in_process"], ("replicas", "distinct_devices", "peer_access_mask"))
+    out["detail"] = os.path.relpath(detail_path or DETAIL_PATH, ROOT)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_MAX_BYTES:                      # (never silently: the driver's parser is what this is for)
+        raise RuntimeError(f"the bench line grew to {len(line)} bytes (> {LINE_MAX_BYTES})")
+    return line
+
+
 
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
@@ -282,7 +391,7 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s, gpu_rows, gpu_counts)
     out = {"value": n_timed / dt, "unit": "queries/s", "cores": 1, "kind": kind,
            "sample": f"first {n_timed} needles of the step batch, limit {limit}, one thread "
                      f"(flags of ext/blurrily/extconf.rb: -Os); rows compared on the first {n}",
-           "ms_per_query": 1e3 * dt / n_timed,
+           "ms_per_query": 1e3 * dt / n_timed, "n_timed": int(n_timed),
            "parity_checked": n, "parity_mismatches": len(mismatches)}
     if mismatches:
         i = mismatches[0]
@@ -489,6 +598,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     # re-measurement INSIDE the timed steps -- every sweep, twice -- is not a step's work; it is stamped, and the steps
     # are timed again, once.  Single rank only: the ranks' timed regions must stay in step.)
     sweep_retunes = 0
+    first_attempt = None                                          # kept when the steps had to be timed again
     for attempt in range(2):
         kernel_ms.clear()
         gather_ms.clear()
@@ -499,8 +609,9 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
         fence()
         elapsed = time.perf_counter() - t0
         sweep_retunes = m.get_option("retunes") - retunes0
-        if sweep_retunes == 0 or world > 1:
+        if sweep_retunes == 0 or world > 1 or attempt == 1:
             break
+        first_attempt = {"ms_per_step": 1e3 * elapsed / steps, "sweep_retunes": int(sweep_retunes)}
         print(f"[bench] the sweep choice was measured again inside the timed steps ({sweep_retunes}x): timing them again", file=sys.stderr)
     coll_dev = "cpu" if host_gather else dev
     if world > 1:
@@ -528,6 +639,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
               3: "needle-major, dense slices left out of the count",
               4: "small haystack: four waves and one window's counters per needle"}
     sweep = sweeps[m.get_option("last_sweep")]                               # of the timed launches
+    timed_kernels = m.last_kernels()                                         # ... and the kernels they ran (blurrily_storage_last_kernels)
     # one more launch, untimed, with the kernels' own request counters on: the physical bytes and the
     # LDS-atomic lanes of exactly this batch -- by the SAME sweep (a measured choice is kept while counting)
     m.set_stats(True)
@@ -686,6 +798,11 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             "entries_per_query": sum_nb / n_q,
             "kernel_ms": k_ms,
             "sweep_retunes": sweep_retunes,
+            # the steps were timed a second time because the library re-measured its sweep choice inside the first
+            # attempt: that attempt's figures stay in the line, so that the published value can be audited
+            "retimed": first_attempt is not None,
+            "first_ms_per_step": first_attempt["ms_per_step"] if first_attempt else None,
+            "sweep_retunes_first_attempt": first_attempt["sweep_retunes"] if first_attempt else 0,
             "roofline": {
                 # what the kernels asked of the memory system in one launch sequence of this batch, counted exactly
                 # in-kernel (blurrily_storage_set_stats) in an extra untimed launch of THIS run; L2 hits included
@@ -736,11 +853,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                               "workload at these sources supports more than the per-step chain (barriers, LDS round trips, one "
                               "global latency: profiles/r04_step_timeline.md)",
                 "kernel_source_hash": kernel_source_hash(),
-                "kernel": ("wsweep_kernel (window-major) + find_kernel<uint8_t,1024> (phase 1)" if sweep == "window-major"
-                           else "find_kernel<uint8_t,1024,false,true,true> (manager + workers; slices left out, settled by bitmap)"
-                           if sweep.startswith("needle-major, dense")
-                           else "find_small_kernel (+ find_kernel<uint8_t,1024,false,true,false> for needles of 16..64 trigrams)"
-                           if sweep.startswith("small") else "find_kernel<uint8_t,1024,false,true,false>"),
+                "kernel": "+".join(timed_kernels),      # what the timed launches ran, from the library
                 "sweep": sweep, "counted_sweep": counted_sweep, "sweep_measured": tuned,
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -823,6 +936,8 @@ def main():
     ap.add_argument("--force-sweep", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="1 needle-major, 2 window-major, 3 needle-major with slices left out: that sweep whatever a "
                          "measurement would say (PMC passes of the sweep a bench run chose: tools/collect_profiles.sh)")
+    ap.add_argument("--detail", default=DETAIL_PATH, metavar="PATH",
+                    help="where the full record goes (the stdout line is the short one the driver parses)")
     ap.add_argument("--static-choice", action="store_true",
                     help="the sweep by the static rule, not by measuring both on the first batch (PMC passes: "
                          "every find call of the run then launches the same kernels)")
@@ -870,7 +985,7 @@ def main():
                 ok = ok and ok_x
                 extra[name] = {k: line[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "p50_query_us", "p99_query_us",
                                                     "matched_entries_per_sec", "entries_per_query", "kernel_ms", "sweep_retunes",
-                                                    "roofline", "cpu_baseline", "parity_checked") if k in line}
+                                                    "retimed", "first_ms_per_step", "roofline", "cpu_baseline", "parity_checked") if k in line}
             except Exception as e:                   # recorded, and the run exits 1
                 import traceback
                 log(f"extra config '{name}' FAILED:\n{traceback.format_exc()}")
@@ -905,7 +1020,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # the whole record beside the script, the short line on stdout (the LAST line of stdout, alone)
+        try:
+            with open(args.detail, "w") as fh:
+                json.dump(out, fh, indent=1)
+            log(f"detail: {args.detail}")
+        except OSError as e:
+            log(f"could not write {args.detail}: {e}")
+        print(compact_line(out, args.detail), flush=True)
     if not ok:
         sys.exit(1)
 

@@ -112,6 +112,7 @@ def lib():
         "blurrily_storage_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_longlong)]),
         "blurrily_storage_device_info_sized": (C.c_size_t, [vp, C.c_void_p, C.c_size_t]),
         "blurrily_storage_tune": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint16]),
+        "blurrily_storage_last_kernels": (C.c_size_t, [vp, C.c_char_p, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -130,5 +131,5 @@ EXPORTED_SYMBOLS = (
     "blurrily_storage_device_info", "blurrily_storage_set_timing",
     "blurrily_storage_set_stats", "blurrily_storage_find_stats",
     "blurrily_storage_set_option", "blurrily_storage_get_option", "blurrily_storage_find_path_flags",
-    "blurrily_storage_device_info_sized", "blurrily_storage_tune",
+    "blurrily_storage_device_info_sized", "blurrily_storage_tune", "blurrily_storage_last_kernels",
 )

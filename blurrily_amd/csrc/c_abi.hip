@@ -76,6 +76,28 @@ struct PendingPut {
 };
 
 struct trigram_map_t;
+namespace {
+// where note_launch() writes: the `last_kernels` of the map whose batch is being enqueued on this thread (run_find_on)
+thread_local std::string* t_launch_names = nullptr;
+}
+namespace blurrily {
+void note_launch(const char* kernel_name) {
+  std::string* s = t_launch_names;
+  if (!s) return;
+  // distinct names, launch order (a window-major batch launches wsweep_kernel once per window)
+  const std::string name(kernel_name);
+  size_t at = 0;
+  while (at <= s->size()) {
+    const size_t end = s->find('+', at);
+    const std::string have = s->substr(at, end == std::string::npos ? std::string::npos : end - at);
+    if (have == name) return;
+    if (end == std::string::npos) break;
+    at = end + 1;
+  }
+  if (!s->empty()) *s += '+';
+  *s += name;
+}
+}
 // "devices" > 1: one more copy of the map's device side, on another visible device (or, with more replicas than
 // devices, on one that already has one): clones of the primary's images, a map object of its own for the scratch
 // buffers, events and measured choices its finds need, a stream, and staging for its shard of a batch.
@@ -128,6 +150,7 @@ struct trigram_map_t {
   float       ws_tuned_ms[8][3] = {};   // what the measurement saw (needle-major, window-major, slices left out)
   int         last_tuned = -1;          // the class measured most recently ("tuned_*_us" report its figures)
   int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2 / 3; 0: none yet)
+  std::string last_kernels;             // the find kernels the last batch on the base image launched, '+'-joined (blurrily_storage_last_kernels)
   size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
   hipEvent_t  tune_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // a measured choice is WATCHED: the chosen sweep's later batches of the class are bracketed by two events (read at the
@@ -306,6 +329,12 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   if (n > 0xFFFFFFF0ull) { errno = EINVAL; return -1; }
   const bool is_base = &ix == &m->dev;                 // (the delta image of pending puts is searched the same way)
   if (is_base) m->last_sweep = 0;
+  struct NameScope {                                   // the launches below note their kernels' names in the map
+    std::string* prev;
+    explicit NameScope(std::string* s) : prev(t_launch_names) { t_launch_names = s; }
+    ~NameScope() { t_launch_names = prev; }
+  } name_scope(is_base ? &m->last_kernels : nullptr);
+  if (is_base) m->last_kernels.clear();
 
   // scratch: codes | per-needle arrays | scalars
   const size_t code_slots = packed_bytes + n;
@@ -1639,6 +1668,16 @@ int blurrily_storage_find_stats(trigram_map m, uint64_t* out8) {
   BLURRILY_HIP_TRY(hipDeviceSynchronize());
   BLURRILY_HIP_TRY(hipMemcpy(out8, m->d_stats, kStatSlots * 8, hipMemcpyDeviceToHost));
   return 0;
+}
+
+size_t blurrily_storage_last_kernels(trigram_map m, char* out, size_t cap) {
+  const std::string& s = m->last_kernels;
+  if (out && cap) {
+    const size_t k = std::min(s.size(), cap - 1);
+    std::memcpy(out, s.data(), k);
+    out[k] = '\0';
+  }
+  return s.size();
 }
 
 int blurrily_storage_find_path_flags(trigram_map m, uint32_t* out, size_t n) {

@@ -128,6 +128,10 @@ enum : uint32_t {
   kStatAllSlots       = 16,
 };
 
+// Every find-kernel launch notes its name here (c_abi.hip keeps, per map, the kernels of the last batch's short-needle
+// launches in launch order: blurrily_storage_last_kernels -- what a bench line names instead of guessing).
+void note_launch(const char* kernel_name);
+
 uint32_t find_pool_cap(uint32_t keep);
 bool find_can_leave(uint32_t keep);   // limits whose pool leaves room for the needle-major sweep's settled candidates (up to ~150)
 int find_threads();

@@ -236,6 +236,10 @@ static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) 
                                          160 * 1024 - int(kWindowSize * sizeof(CT))));   // static counters
   hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT, LEAVE>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
+  char name[64];
+  std::snprintf(name, sizeof name, "find_kernel<%s,%d,%s,%s,%s>", sizeof(CT) == 1 ? "uint8_t" : "uint16_t", NT,
+                RANGED ? "true" : "false", SHORT ? "true" : "false", LEAVE ? "true" : "false");
+  ::blurrily::note_launch(name);
   return 0;
 }
 
@@ -284,6 +288,7 @@ int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, boo
   const uint32_t grid = std::min(chunks, n_cus * 4u);
   hipLaunchKernelGGL(wsweep_kernel, dim3(grid), dim3(kWsNT), 0, stream, a, w, n, chunk_len, own_pass ? 1u : 0u);
   BLURRILY_HIP_TRY(hipGetLastError());
+  ::blurrily::note_launch("wsweep_kernel");
   return 0;
 }
 
@@ -292,6 +297,7 @@ int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream) {
   const uint32_t grid = std::min(a.n_work, n_cus * 4u);       // four workgroups per CU (LDS: 35 KiB each)
   hipLaunchKernelGGL(find_small_kernel, dim3(grid), dim3(kWsNT), 0, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
+  ::blurrily::note_launch("find_small_kernel");
   return 0;
 }
 

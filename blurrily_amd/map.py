@@ -229,6 +229,13 @@ class RawMap:
             _raise_errno()
         return out
 
+    def last_kernels(self):
+        """Names of the find kernels the last batched find launched, in launch order (blurrily_storage_last_kernels)."""
+        self._check_open()
+        buf = C.create_string_buffer(512)
+        self._lib.blurrily_storage_last_kernels(self._h, buf, len(buf))
+        return [k for k in buf.value.decode().split("+") if k]
+
     def tune(self, packed, offsets, n, limit):
         """Measure now which sweep serves batches of n needles at this limit (blurrily_storage_tune): the needles
         given, repeated up to n, go through every sweep the class can take."""

@@ -240,6 +240,11 @@ int  blurrily_storage_find_stats(trigram_map haystack, uint64_t* out8);
  * Copies the words of the first n needles of the LAST such call.  The parity tests use it to compare
  * needles of every class row for row.  0, or -1 with errno EINVAL (no such call, n too large). */
 int  blurrily_storage_find_path_flags(trigram_map haystack, uint32_t* out, size_t n);
+/* The find kernels the LAST batched find on this map launched for its needles, in launch order, distinct names joined by
+ * '+' (e.g. "find_kernel<uint8_t,1024,false,true,true>", "find_small_kernel+find_kernel<uint8_t,1024,false,true,false>",
+ * "find_kernel<uint8_t,1024,false,true,false>+wsweep_kernel"): what a measured sweep choice actually ran, for a bench
+ * line or a profile to name.  NUL-terminated into out[cap] (truncated to cap - 1); returns the untruncated length. */
+size_t blurrily_storage_last_kernels(trigram_map haystack, char* out, size_t cap);
 
 /* Tunables (no reference counterpart; nothing on the find path reads the environment).
  * Per map -- read by the map's next find; calls on one map are serial, as in the reference:

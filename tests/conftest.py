@@ -62,18 +62,25 @@ def geonames_full():
     return _FullGeonames()
 
 
-def two_ranks_command(port):
+TWO_RANKS_DETAIL = "/tmp/blurrily_two_ranks_detail_%d.json" % os.getpid()
+
+
+def two_ranks_command(port, detail=TWO_RANKS_DETAIL):
     """bench.py's N > 1 path as two ranks sharing this box's GPU over gloo (tests/test_gpu_bench_batch.py:
     test_bench_two_ranks_plumbing)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-            "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"]
+            "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05", "--detail", detail]
 
 
+@pytest.hookimpl(trylast=True)
 def pytest_collection_modifyitems(config, items):
     """That run is a minute of two fresh interpreters importing torch: started when the session starts, it overlaps the
     first tests instead of standing in the driver's clock; the test collects it (a plumbing test: nothing in it, or in
-    the tests it overlaps, asserts on a time)."""
+    the tests it overlaps, asserts on a time).  Last of the collection hooks, so that `items` is what -k / -m / --deselect
+    left; never under --collect-only; pytest_sessionfinish kills it if the test that collects it never ran."""
+    if config.getoption("collectonly", False):
+        return
     if not any(it.name == "test_bench_two_ranks_plumbing" for it in items) or not _gpu_available():
         return
     import socket
@@ -86,6 +93,26 @@ def pytest_collection_modifyitems(config, items):
         import __graft_entry__ as g
         g.build()                                            # (the ranks load the built library)
         config._two_ranks = subprocess.Popen(two_ranks_command(port), env=env, cwd=ROOT, stdout=subprocess.PIPE,
-                                             stderr=subprocess.PIPE, text=True)
+                                             stderr=subprocess.PIPE, text=True, start_new_session=True)   # (its own process group: killed whole)
     except Exception:
         config._two_ranks = None
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The two-rank bench run started with the session (above) does not outlive it: an aborted or -x-stopped session
+    would otherwise leave a minute of GPU work behind."""
+    proc = getattr(session.config, "_two_ranks", None)
+    if proc is not None and proc.poll() is None:
+        import signal
+        try:
+            os.killpg(os.getpgid(proc.pid), signal.SIGTERM)
+        except Exception:
+            proc.terminate()
+        try:
+            proc.wait(timeout=20)
+        except Exception:
+            proc.kill()
+    try:
+        os.unlink(TWO_RANKS_DETAIL)
+    except OSError:
+        pass

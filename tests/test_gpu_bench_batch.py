@@ -189,8 +189,17 @@ def test_bench_two_ranks_plumbing(tmp_path, request):
                              text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         out = res.stdout
+    from conftest import TWO_RANKS_DETAIL
     line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    short = json.loads(line)
+    assert len(line) <= 6000                                   # what the driver parses: short, numbers and tokens
+    # the line names the collective and the devices it ran on; everything else is in the detail file
+    assert short["n_gpus"] == min(2, __import__("torch").cuda.device_count()) and short["replicas"] == 2
+    assert short["collective"]["backend"] == "gloo" and short["collective"]["world"] == 2 and "rccl_version" in short["collective"]
+    assert len(short["per_rank_kernel_ms"]) == 2 and short["gather_checked"] == 2
+    with open(TWO_RANKS_DETAIL) as fh:
+        d = json.load(fh)
+    assert d["value"] == __import__("pytest").approx(short["value"], rel=1e-3)
     # n_gpus counts PHYSICAL devices (two ranks on this box's one GPU are one GPU); `replicas` the shards
     import torch
     phys = min(2, torch.cuda.device_count())
@@ -223,13 +232,24 @@ def test_bench_two_ranks_strong_scaling_plumbing():
     env = dict(os.environ, BLURRILY_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--scale", "0.02", "--scaling", "strong"]
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--scale", "0.02", "--scaling", "strong",
+           "--detail", f"/tmp/blurrily_strong_detail_{os.getpid()}.json"]
     res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    short = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    with open(cmd[-1]) as fh:
+        d = json.load(fh)
+    os.unlink(cmd[-1])
     total = 8 * 20000
+    # one GPU served both ranks: the line says so (n_gpus 1, replicas 2), names the collective, and counts every rank's
+    # needles once
+    import torch
+    phys = min(2, torch.cuda.device_count())
+    assert short["n_gpus"] == phys and short["replicas"] == 2 and short["scaling"] == "strong"
+    assert short["collective"] == {"backend": "gloo", "world": 2, "rccl_version": None, "distinct_devices": phys}
     assert d["scaling"] == "strong" and d["replicas"] == 2 and d["config"]["needles_per_gpu"] == total // 2
     assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert abs(short["value"] - d["value"]) / d["value"] < 1e-3
 
 
 def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
@@ -245,15 +265,20 @@ def test_bench_n1_under_the_launcher_is_the_plain_n1_line():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    detail = f"/tmp/blurrily_n1_detail_{os.getpid()}.json"
     tail = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scale", "0.05",
-            "--no-extra", "--no-cpu-baseline", "--latency-probes", "0"]
+            "--no-extra", "--no-cpu-baseline", "--latency-probes", "0", "--detail", detail]
     lines = []
     for launcher in ([], ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", str(port)]):
         res = subprocess.run([sys.executable] + launcher + tail, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
-        lines.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]))
+        short = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+        assert short["n_gpus"] == 1 and "collective" not in short and short["roofline"]["kernel"].startswith("find_")
+        with open(detail) as fh:
+            lines.append(json.load(fh))
+        os.unlink(detail)
     plain, launched = lines
     assert plain["n_gpus"] == launched["n_gpus"] == 1 and "collective" not in launched and "per_rank" not in launched
     assert plain["config"] == launched["config"] and plain["metric"] == launched["metric"]
@@ -276,10 +301,19 @@ def _run_bench(args, timeout=900):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, text=True, timeout=timeout)
+    detail = f"/tmp/blurrily_bench_detail_{os.getpid()}.json"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--detail", detail], cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    return res, (json.loads(lines[-1]) if lines else None)
+    if not lines:
+        return res, None
+    # the full record (what these tests look into), with the short line the driver parses under "_line"
+    assert len(lines[-1]) <= 6000, len(lines[-1])
+    with open(detail) as fh:
+        d = json.load(fh)
+    os.unlink(detail)
+    d["_line"] = json.loads(lines[-1])
+    return res, d
 
 
 def test_bench_fails_loudly_when_a_leg_fails():
@@ -289,6 +323,8 @@ def test_bench_fails_loudly_when_a_leg_fails():
                          "--inject-failure", "words"])
     assert res.returncode == 1, (res.returncode, res.stderr[-1500:])
     assert d is not None and "injected failure" in d["extra_configs"]["words"]["cpu_baseline"]["error"]
+    assert "injected failure" in d["_line"]["extra_configs"]["words"]["cpu_error"]        # ... and in the short line too
+    assert d["_line"]["cpu_baseline"]["parity_mismatches"] == 0 and d["_line"]["cpu_baseline"]["parity_checked"] >= 64
     # the legs that did not fail are whole, parity floor included (32 needles whatever the budget)
     assert d["cpu_baseline"]["parity_mismatches"] == 0 and d["parity_checked"] >= 64
     for name in ("skewed", "geonames_x4", "geonames_miss"):
@@ -298,6 +334,7 @@ def test_bench_fails_loudly_when_a_leg_fails():
     res, d = _run_bench(["--steps", "2", "--warmup", "1", "--scale", "0.02", "--cpu-budget", "1", "--latency-probes", "0",
                          "--no-extra", "--inject-failure", "geonames"])
     assert res.returncode == 1 and "injected failure" in d["cpu_baseline"]["error"]
+    assert "injected failure" in d["_line"]["cpu_baseline"]["error"]
 
 
 def test_bench_in_process_over_two_logical_devices():
