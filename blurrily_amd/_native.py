@@ -115,7 +115,12 @@ def lib():
         "blurrily_storage_last_kernels": (C.c_size_t, [vp, C.c_char_p, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(L, name)
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            if os.environ.get("BLURRILY_LIB"):      # (an older build of the library under A/B: it lacks the newer entry points)
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = L
