@@ -32,6 +32,7 @@ n_q = len(qo) - 1
 m.set_timing(True)
 ms = [[] for _ in sets]
 crc = [None] * len(sets)
+crcs = [set() for _ in sets]
 for r in range(reps):
     for i, st in enumerate(sets):
         for k, v in st.items():
@@ -40,7 +41,8 @@ for r in range(reps):
         ms[i].append(m.device_info()["last_find_kernel_ms"])
         live = np.arange(limit)[None, :] < counts[:, None].astype(np.int64)
         crc[i] = zlib.crc32(np.ascontiguousarray(np.where(live[:, :, None], rows, 0)).tobytes()) ^ zlib.crc32(counts.tobytes())
+        crcs[i].add(crc[i])
 tag = os.path.basename(os.environ.get("BLURRILY_LIB", "current"))
 for i, st in enumerate(sets):
-    print(f"{tag} {name} n={n_q} sweep {m.get_option('last_sweep')} {st}: crc {crc[i]:08x} kernel ms " +
+    print(f"{tag} {name} n={n_q} sweep {m.get_option('last_sweep')} {st}: crc {crc[i]:08x}{' UNSTABLE ' + ','.join(f'{c:08x}' for c in crcs[i]) if len(crcs[i]) > 1 else ''} kernel ms " +
           " ".join(f"{x:.1f}" for x in ms[i]) + f"  min {min(ms[i]):.1f}", flush=True)
