@@ -139,7 +139,6 @@ struct trigram_map_t {
   uint32_t    ws_cmin = 3;              // a left-out slice must leave at least this many counted matches
   uint32_t    nm_cmin = 3;              // the same for the needle-major sweep (0: it leaves nothing out)
   uint32_t    nm_dense = 4096;          // ... which leaves out slices of at least this many postings only
-  uint32_t    nm_pow2 = 0;              // ... up to this many fewer where that makes the scan's bound a power of two (0: never)
   bool        small_sweep = true;       // images of at most kSmallMaxWindows windows: find_small_kernel serves large batches at limits up to 64
   uint32_t    small_min_needles = 4096; // ... from this many needles on (below: two chains per CU are not the limit)
   uint32_t    nm_min_windows = 256;     // ... and, where the choice is not measured, on images of at least this many windows
@@ -377,7 +376,6 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   a.dense_min8 = ix.dense_min8;
   a.nm_dense = std::max((m->nm_dense + 7u) & ~7u, ix.dense_min8);
   a.nm_cmin = 0;                                     // (set per launch sequence: see "WHICH sweep" below)
-  a.nm_pow2 = m->nm_pow2;
   a.stats = m->collect_stats ? m->d_stats : nullptr;
   const bool cb = a.stats != nullptr;
   if (cb) {                                          // wave 0's phase clocks per workgroup (counted build only)
@@ -788,7 +786,7 @@ int ensure_replicas(trigram_map m) {
   for (Replica& r : m->replicas) {
     trigram_map s = r.side;
     // options and measured choices follow the primary's
-    s->build_opt = m->build_opt; s->ws_cmin = m->ws_cmin; s->nm_cmin = m->nm_cmin; s->nm_dense = m->nm_dense; s->nm_pow2 = m->nm_pow2;
+    s->build_opt = m->build_opt; s->ws_cmin = m->ws_cmin; s->nm_cmin = m->nm_cmin; s->nm_dense = m->nm_dense;
     s->ws_min_needles = m->ws_min_needles; s->ws_autotune = m->ws_autotune; s->ws_static_slice = m->ws_static_slice;
     s->nm_min_windows = m->nm_min_windows; s->small_sweep = m->small_sweep; s->small_min_needles = m->small_min_needles;
     for (int c = 0; c < 8; ++c) if (m->ws_choice[c]) s->ws_choice[c] = m->ws_choice[c];
@@ -1555,7 +1553,7 @@ constexpr OptionSlot kMapOptions[] = {
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
     {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
     {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20},
-    {"retunes", 0, 0}, {"tune_inject", 0, 3}, {"nm_pow2", 0, 8}};
+    {"retunes", 0, 0}, {"tune_inject", 0, 3}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1604,7 +1602,6 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 23: m->one.min_per = uint32_t(value); return 0;
     case 24: return 0;                                   // (read-only)
     case 25: m->tune_inject = int(value); return 0;      // (tests: the next measurement's bad sample)
-    case 26: m->nm_pow2 = uint32_t(value); break;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1650,7 +1647,6 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 23: *value = m->one.min_per; return 0;
     case 24: *value = (long long)m->retunes; return 0;
     case 25: *value = m->tune_inject; return 0;
-    case 26: *value = m->nm_pow2; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -51,7 +51,6 @@ struct FindArgs {
   // (nm_cmin 0: nothing is ever left out)
   uint32_t        nm_dense;
   uint32_t        nm_cmin;
-  uint32_t        nm_pow2;     // 0: off; n: up to n slices fewer are left out where that makes the scan's bound a power of two
   // window-major sweep (wsweep_kernel)
   uint32_t        own_only;    // find_kernel: sweep only the window pair of the needle's own length class and leave
                                // the best keys (not rows) in `results` as the needle's state for wsweep_kernel
