@@ -179,12 +179,15 @@ struct trigram_map_t {
   // sequence word into, the per-workgroup lists and the ticket on the device
   struct One {
     hipStream_t    stream = nullptr;
-    unsigned char* h_out = nullptr;     // [kOneMaxNeedles][kOneMaxKeep] rows | [kOneMaxNeedles][2] count, sequence word
+    unsigned char* h_out = nullptr;     // per image: [kMidMaxNeedles][kOneMaxKeep] rows | [..][2] count, sequence word | codes | T (kOneHostBytes)
     unsigned char* d_out = nullptr;     // the same memory as the device addresses it
-    DeviceBuffer   d_parts;             // [kOneMaxNeedles][kOneMaxGrid * kOneMaxKeep] keys | [kOneMaxNeedles][kOneMaxGrid] flags
+    DeviceBuffer   d_parts;             // per image: [kOneMaxLists][kOneMaxKeep] keys | [kOneMaxLists] flags | [kMidMaxNeedles] tickets
     uint32_t       seq = 0;
     bool           enabled = true;      // option "one_launch"
     uint32_t       min_per = 0;         // option "one_windows_per_wg": at least this many windows per workgroup (0: as few as the grid allows)
+    uint32_t       mid_workgroups = 1024;   // option "mid_workgroups": workgroups a launch of more than kOneMaxNeedles needles aims at
+    uint32_t       few_max = 32;        // option "few_max": host-buffer batches of up to this many needles share find_one_kernel's launch
+                                        // (up to kMidMaxNeedles; from about forty needles on latency mode's ranges are faster: DESIGN.md)
     uint64_t       taken = 0;           // finds served this way (option "one_taken", read-only)
   } one;
   // large host-buffer batches go in chunks through a three-stream pipeline (find_batch_chunked)
@@ -1188,9 +1191,9 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
 static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                            trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii) {
   if (n == 0) return 0;
-  if (!raw && n <= kOneMaxNeedles) {                  // a handful of needles: they share ONE launch (find_few)
-    const char* s[kOneMaxNeedles];
-    size_t len[kOneMaxNeedles];
+  if (!raw && n <= m->one.few_max) {                  // a handful of needles: ONE launch (find_few; option "few_max")
+    const char* s[kMidMaxNeedles];
+    size_t len[kMidMaxNeedles];
     for (size_t i = 0; i < n; ++i) {
       s[i] = packed + offsets[i];
       const size_t cap = size_t(offsets[i + 1] - offsets[i]);
@@ -1293,14 +1296,21 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
 // timing or request counters switched on, option "one_launch" 0.  Mutations the base image does not hold yet are
 // served: tombstones inside the select, pending puts by a second launch over the delta image.
 constexpr size_t kOneRowBytes = kOneMaxKeep * sizeof(trigram_match_t);
-constexpr size_t kOneHostBytes = kOneMaxNeedles * (kOneRowBytes + 8) + 64;
+// the pinned page per image: [kMidMaxNeedles] rows | [kMidMaxNeedles][2] count, sequence word | codes [kMidMaxNeedles][64] | T
+constexpr size_t kOneWordsAt = kMidMaxNeedles * kOneRowBytes;
+constexpr size_t kOneCodesAt = kOneWordsAt + kMidMaxNeedles * 8 + 64;
+constexpr size_t kOneTAt = kOneCodesAt + kMidMaxNeedles * 64 * sizeof(uint16_t);
+constexpr size_t kOneHostBytes = kOneTAt + kMidMaxNeedles * sizeof(uint32_t) + 64;
+// lists a launch may leave: up to sixteen rows of kOneMaxGrid workgroups, or more rows of fewer (find_few aims at a
+// thousand workgroups in all)
+constexpr size_t kOneMaxLists = size_t(kOneMaxNeedles) * kOneMaxGrid;
 
 static int find_few(trigram_map m, const char* const* s, const size_t* len, size_t n, uint16_t limit, trigram_match results,
                     uint32_t* counts) {
-  if (!m->one.enabled || limit == 0 || limit > kOneMaxKeep || n == 0 || n > kOneMaxNeedles || m->timing || m->collect_stats)
+  if (!m->one.enabled || limit == 0 || limit > kOneMaxKeep || n == 0 || n > kMidMaxNeedles || m->timing || m->collect_stats)
     return kOneNotTaken;
-  uint16_t codes[kOneMaxNeedles * 64];
-  uint32_t T[kOneMaxNeedles];
+  uint16_t codes[kMidMaxNeedles * 64];
+  uint32_t T[kMidMaxNeedles];
   {
     uint16_t buf[256];
     for (size_t i = 0; i < n; ++i) {
@@ -1322,7 +1332,7 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   // merged here (they hold disjoint references).  A log that has overflowed is folded by ensure_device above.
   const bool with_tomb = log_of(m)->n_tomb != 0, with_delta = !log_of(m)->pending.empty() && m->delta.device >= 0;
   // needles without a posting return no rows (storage.c:503) and take no row of the grid
-  uint32_t row_of[kOneMaxNeedles], n_rows = 0;
+  uint32_t row_of[kMidMaxNeedles], n_rows = 0;
   for (size_t i = 0; i < n; ++i) {
     uint64_t nb = 0;
     for (uint32_t k = 0; k < T[i]; ++k) nb += m->host->bucket(codes[i * 64 + k]).used;
@@ -1333,18 +1343,37 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   }
   if (n_rows == 0) return 0;
   auto& O = m->one;
-  if (!O.stream) {
-    BLURRILY_HIP_TRY(hipStreamCreateWithFlags(&O.stream, hipStreamNonBlocking));
-    BLURRILY_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&O.h_out), 2 * kOneHostBytes,
-                                   hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(O.h_out, 0, 2 * kOneHostBytes);
-    BLURRILY_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&O.d_out), O.h_out, 0));
+  if (!O.h_out) {
+    // stream, pinned page and its device address: built in locals and kept only when ALL of them exist (a half-made set
+    // -- a stream without its page -- would have the next find skip this block and poll a null page)
+    hipStream_t st = nullptr;
+    unsigned char *h = nullptr, *d = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h), 2 * kOneHostBytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0);
+    if (e != hipSuccess) {
+      std::fprintf(stderr, "blurrily_hip: the single find's stream / pinned page: %s\n", hipGetErrorString(e));
+      if (h) (void)hipHostFree(h);
+      if (st) (void)hipStreamDestroy(st);
+      errno = (e == hipErrorOutOfMemory) ? ENOMEM : EIO;
+      return -1;
+    }
+    std::memset(h, 0, 2 * kOneHostBytes);
+    O.stream = st; O.h_out = h; O.d_out = d;
   }
   if (with_tomb && apply_tombstones(m, O.stream) < 0) return -1;       // (deletes since the last find: their bits are set first)
-  const size_t key_bytes = size_t(kOneMaxNeedles) * kOneMaxGrid * kOneMaxKeep * 8, flag_bytes = size_t(kOneMaxNeedles) * kOneMaxGrid * 4;
+  const size_t key_bytes = kOneMaxLists * kOneMaxKeep * 8, flag_bytes = kOneMaxLists * 4, ticket_bytes = kMidMaxNeedles * 4;
+  const size_t part_bytes = key_bytes + flag_bytes + ticket_bytes;
   if (!O.d_parts.p) {
-    if (O.d_parts.reserve(2 * (key_bytes + flag_bytes), O.stream) < 0) return -1;
-    BLURRILY_HIP_TRY(hipMemsetAsync(O.d_parts.p, 0, 2 * (key_bytes + flag_bytes), O.stream));
+    if (O.d_parts.reserve(2 * part_bytes, O.stream) < 0) return -1;
+    BLURRILY_HIP_TRY(hipMemsetAsync(O.d_parts.p, 0, 2 * part_bytes, O.stream));
+  }
+  // more than kOneMaxNeedles rows: the codes travel in the pinned page (both images' launches read the first image's copy)
+  const bool far = n_rows > kOneMaxNeedles;
+  if (far) {
+    std::memcpy(O.h_out + kOneCodesAt, codes, size_t(n_rows) * 64 * sizeof(uint16_t));
+    std::memcpy(O.h_out + kOneTAt, T, size_t(n_rows) * sizeof(uint32_t));
+    __atomic_thread_fence(__ATOMIC_RELEASE);
   }
   const uint32_t seq = ++O.seq ? O.seq : ++O.seq;         // (never 0: what the words hold before the first find)
   // one launch per image: [0] the base image, [1] the delta image of the pending puts (its own lists, flags and rows)
@@ -1359,16 +1388,27 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
     if (which == 0) a.phase_clocks = m->d_phase;       // (trace build: find_one_kernel's wall-clock marks, 16 per workgroup)
 #endif
-    // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond
+    // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond; more than
+    // eight needles: about a thousand workgroups in all -- two rounds of what the chip holds --, i.e. several
+    // window pairs a workgroup (its later steps arrive with its own threshold: one_select's cheap way)
     uint32_t per = 1;
     if (ix.n_windows > kOneMaxGrid) { per = (ix.n_windows + kOneMaxGrid - 1) / kOneMaxGrid; per += per & 1u; }
+    if (n_rows > 8) {                                     // (from nine needles on: measured, tools/mid_probe.py)
+      const uint32_t rows_wgs = std::max<uint32_t>(2u, m->one.mid_workgroups / n_rows);     // workgroups per needle
+      const uint32_t per_far = (ix.n_windows + rows_wgs - 1) / rows_wgs;
+      per = std::max(per, per_far + (per_far > 1 ? per_far & 1u : 0u));
+    }
     per = std::max(per, O.min_per);                       // (a test's way to the several-steps-per-workgroup path on a small image)
     const uint32_t grid = (ix.n_windows + per - 1) / per;
-    unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p) + which * (key_bytes + flag_bytes);
+    if (size_t(grid) * n_rows > kOneMaxLists) { errno = EINVAL; return -1; }   // (cannot happen: grid <= kOneMaxGrid, far grids are small)
+    unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p) + which * part_bytes;
     unsigned char* d_rows = O.d_out + which * kOneHostBytes;
     return launch_find_one(a, codes, T, n_rows, per, grid, reinterpret_cast<unsigned long long*>(dp),
                            reinterpret_cast<uint32_t*>(dp + key_bytes), reinterpret_cast<trigram_match_t*>(d_rows),
-                           reinterpret_cast<uint32_t*>(d_rows + kOneMaxNeedles * kOneRowBytes), seq, O.stream);
+                           reinterpret_cast<uint32_t*>(d_rows + kOneWordsAt), seq, O.stream,
+                           far ? reinterpret_cast<const uint16_t*>(O.d_out + kOneCodesAt) : nullptr,
+                           far ? reinterpret_cast<const uint32_t*>(O.d_out + kOneTAt) : nullptr,
+                           far ? reinterpret_cast<uint32_t*>(dp + key_bytes + flag_bytes) : nullptr);
   };
   if (launch_on(m->dev, with_tomb ? m->dev.d_tomb : nullptr, 0) < 0) return -1;
   if (with_delta && launch_on(m->delta, nullptr, 1) < 0) return -1;
@@ -1376,7 +1416,7 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   // runtime to notice the kernel's completion signal (an interrupt or a slower poll: 10 us and more).
   uint64_t spins = 0;
   for (int which = 0; which < (with_delta ? 2 : 1); ++which) {
-    volatile uint32_t* words = reinterpret_cast<volatile uint32_t*>(O.h_out + which * kOneHostBytes + kOneMaxNeedles * kOneRowBytes);
+    volatile uint32_t* words = reinterpret_cast<volatile uint32_t*>(O.h_out + which * kOneHostBytes + kOneWordsAt);
     for (uint32_t r = 0; r < n_rows; ++r) {
       while (words[2 * r + 1] != seq) {
 #if defined(__x86_64__)
@@ -1391,8 +1431,8 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  const volatile uint32_t* w0 = reinterpret_cast<const volatile uint32_t*>(O.h_out + kOneMaxNeedles * kOneRowBytes);
-  const volatile uint32_t* w1 = reinterpret_cast<const volatile uint32_t*>(O.h_out + kOneHostBytes + kOneMaxNeedles * kOneRowBytes);
+  const volatile uint32_t* w0 = reinterpret_cast<const volatile uint32_t*>(O.h_out + kOneWordsAt);
+  const volatile uint32_t* w1 = reinterpret_cast<const volatile uint32_t*>(O.h_out + kOneHostBytes + kOneWordsAt);
   for (uint32_t r = 0; r < n_rows; ++r) {
     const uint32_t i = row_of[r];
     const trigram_match_t* a_rows = reinterpret_cast<const trigram_match_t*>(O.h_out + r * kOneRowBytes);
@@ -1553,7 +1593,7 @@ constexpr OptionSlot kMapOptions[] = {
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
     {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
     {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20},
-    {"retunes", 0, 0}, {"tune_inject", 0, 3}};
+    {"retunes", 0, 0}, {"tune_inject", 0, 3}, {"mid_workgroups", 64, 1 << 16}, {"few_max", 1, kMidMaxNeedles}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1602,6 +1642,8 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 23: m->one.min_per = uint32_t(value); return 0;
     case 24: return 0;                                   // (read-only)
     case 25: m->tune_inject = int(value); return 0;      // (tests: the next measurement's bad sample)
+    case 26: m->one.mid_workgroups = uint32_t(value); return 0;
+    case 27: m->one.few_max = uint32_t(value); return 0;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1647,6 +1689,8 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 23: *value = m->one.min_per; return 0;
     case 24: *value = (long long)m->retunes; return 0;
     case 25: *value = m->tune_inject; return 0;
+    case 26: *value = m->one.mid_workgroups; return 0;
+    case 27: *value = m->one.few_max; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -146,16 +146,20 @@ int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
 // per CU; needles with 16..64 distinct trigrams are appended to a.over_list.  keep <= kSmallMaxKeep, single pass.
 int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream);
 constexpr uint32_t kSmallMaxKeep = 64, kSmallMaxWindows = 8;
-// ONE needle, the caller waiting (blurrily_storage_find) -- or a handful: one launch, no copies.  The needles' codes travel
-// as kernel arguments (codes[i * 64 ..], T[i] of them), row i of the grid is needle i's: workgroup g of it sweeps windows
-// [g * per, (g + 1) * per), the row's last workgroup merges the per-workgroup lists and writes rows, count and `seq` into
-// host-coherent memory (out_rows[i][kOneMaxKeep], out_count[i][2]).  T <= 64 distinct trigrams, a.keep <= kOneMaxKeep,
-// grid <= kOneMaxGrid, n_needles <= kOneMaxNeedles, a.tomb == nullptr; part_keys [n_needles][grid * keep], flags
-// [n_needles][grid] (any value but `seq`: a launch's workgroups set theirs to it).  Timed build only.
-constexpr uint32_t kOneMaxKeep = 120, kOneMaxGrid = 256, kOneMaxNeedles = 16;
+// ONE needle, the caller waiting (blurrily_storage_find) -- or a handful, or a server's coalesced FINDs (up to
+// kMidMaxNeedles): one launch, no copies.  Row i of the grid is needle i's: workgroup g of it sweeps windows
+// [g * per, (g + 1) * per) and leaves its best keys; one workgroup of the row merges the row's lists and writes rows, count
+// and `seq` into host-coherent memory (out_rows[i][kOneMaxKeep], out_count[i][2]).  Up to kOneMaxNeedles needles travel
+// as kernel arguments (codes[i * 64 ..], T[i] of them; codes_far / T_far / tickets nullptr) and the row's LAST workgroup
+// merges, waiting for the others' flags (any value but `seq`: a launch's workgroups set theirs to it); more needles are
+// read from host-coherent memory (codes_far [n][64], T_far [n]) and the workgroup that finishes last merges (tickets [n],
+// zero between launches).  T <= 64 distinct trigrams, a.keep <= kOneMaxKeep, grid <= kOneMaxGrid; a.tomb: the select
+// drops deleted references; part_keys [n_needles][grid * keep], flags [n_needles][grid].  Timed build only.
+constexpr uint32_t kOneMaxKeep = 120, kOneMaxGrid = 256, kOneMaxNeedles = 16, kMidMaxNeedles = 128;
 int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T, uint32_t n_needles, uint32_t per, uint32_t grid,
                     unsigned long long* part_keys, uint32_t* flags, trigram_match_t* out_rows,
-                    uint32_t* out_count, uint32_t seq, hipStream_t stream);
+                    uint32_t* out_count, uint32_t seq, hipStream_t stream, const uint16_t* codes_far = nullptr,
+                    const uint32_t* T_far = nullptr, uint32_t* tickets = nullptr);
 // Window-major sweep of window `w` over needles [0, n) (those with <= 64 distinct trigrams); a.queue must
 // be a zeroed word of its own.  own_pass: only the needles whose own length class lives in this window
 // pair -- the launches that seed the states (counts[] zeroed before the first of them); else the others.

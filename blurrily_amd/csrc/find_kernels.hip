@@ -303,12 +303,15 @@ int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream) {
 
 int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T, uint32_t n_needles, uint32_t per, uint32_t grid,
                     unsigned long long* part_keys, uint32_t* flags, trigram_match_t* out_rows,
-                    uint32_t* out_count, uint32_t seq, hipStream_t stream) {
+                    uint32_t* out_count, uint32_t seq, hipStream_t stream, const uint16_t* codes_far, const uint32_t* T_far,
+                    uint32_t* tickets) {
   OneArgs o;
+  const bool far = codes_far != nullptr;               // (the needles' codes are read from host-coherent memory: see OneArgs)
   for (uint32_t i = 0; i < kOneMaxNeedles; ++i) {
-    o.T[i] = i < n_needles ? T[i] : 0u;
-    for (uint32_t t = 0; t < 64; ++t) o.codes[i][t] = i < n_needles && t < T[i] ? codes[i * 64 + t] : uint16_t(0);
+    o.T[i] = !far && i < n_needles ? T[i] : 0u;
+    for (uint32_t t = 0; t < 64; ++t) o.codes[i][t] = !far && i < n_needles && t < T[i] ? codes[i * 64 + t] : uint16_t(0);
   }
+  o.codes_far = codes_far; o.T_far = T_far; o.tickets = tickets;
   o.per = per; o.part_keys = part_keys; o.flags = flags;
   o.out_rows = out_rows; o.out_count = out_count; o.seq = seq;
   // ONE needle: its workgroups have their CUs to themselves (24 KiB of dynamic LDS nobody touches keep a second one off:
@@ -320,6 +323,7 @@ int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(kOneAloneLds)));
   hipLaunchKernelGGL((find_one_kernel<kOneThreads>), dim3(grid, n_needles), dim3(kOneThreads), n_needles == 1 ? kOneAloneLds : 0, stream, a, o);
   BLURRILY_HIP_TRY(hipGetLastError());
+  ::blurrily::note_launch("find_one_kernel<1024>");
   return 0;
 }
 

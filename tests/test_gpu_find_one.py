@@ -206,12 +206,16 @@ def test_mutations_the_image_has_not_absorbed(geo):
 
 
 def test_a_handful_of_needles_share_one_launch(geo):
-    """blurrily_storage_find_batch with up to sixteen needles: one launch, a row of the grid per needle (c_abi.hip:
-    find_few) -- each element still exactly one blurrily_storage_find; needles without a posting take no row; the
-    seventeenth needle sends the batch the old way."""
+    """blurrily_storage_find_batch with up to "few_max" needles (32; the kernel takes up to 128): one launch, a row of the
+    grid per needle (c_abi.hip: find_few) -- each element still exactly one blurrily_storage_find; needles without a
+    posting take no row.  Up to sixteen needles travel as kernel arguments and the row's last workgroup merges; more are
+    read from the pinned page and the workgroup that finishes last merges (tickets).  A batch beyond few_max, or a limit
+    beyond 120, goes the old way."""
     m, chk, strings = geo
     rng = np.random.default_rng(8)
-    for n, limit in [(2, 10), (5, 1), (16, 10), (16, 120), (9, 64), (17, 10), (3, 121)]:
+    few_max = m.get_option("few_max")
+    assert few_max == 32
+    for n, limit in [(2, 10), (5, 1), (16, 10), (16, 120), (9, 64), (17, 10), (32, 10), (24, 120), (33, 10), (3, 121)]:
         picks = [strings[int(k)] for k in rng.integers(0, len(strings), size=n)]
         needles = [p[: max(1, len(p) - 1)] for p in picks]
         if n >= 5:
@@ -223,7 +227,33 @@ def test_a_handful_of_needles_share_one_launch(geo):
         went = m.get_option("one_taken") - taken
         for i, nd in enumerate(needles):
             assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (n, limit, nd)
-        if n <= 16 and limit <= 120:
+        if n <= few_max and limit <= 120:
             assert went == sum(1 for nd in needles if chk.find(nd, 1))    # one row per needle that has any posting ...
         else:
             assert went == 0                                   # ... and none when the batch goes the old way
+
+
+@pytest.mark.parametrize("n", [17, 32, 64, 128])
+def test_a_servers_coalesced_finds_share_one_launch(geo, n):
+    """The same launch for up to 128 needles (option "few_max" raised to the kernel's limit): codes from the pinned page, a
+    ticket per row, a handful of window pairs per workgroup ("mid_workgroups" picks how many) -- rows equal the live
+    reference's for every needle, at two limits and two grid shapes, twice in a row (the tickets return to zero)."""
+    m, chk, strings = geo
+    rng = np.random.default_rng(80 + n)
+    m.set_option("few_max", 128)
+    try:
+        for limit, wgs in [(10, 1024), (100, 256)]:
+            m.set_option("mid_workgroups", wgs)
+            for rep in range(2):
+                picks = [strings[int(k)] for k in rng.integers(0, len(strings), size=n)]
+                needles = [p[: max(1, len(p) - 1)] if k % 3 else p for k, p in enumerate(picks)]
+                needles[2] = b""
+                packed, off = _pack(needles)
+                taken = m.get_option("one_taken")
+                rows, counts = m.find_batch_packed(packed, off, limit)
+                assert m.get_option("one_taken") - taken == sum(1 for nd in needles if chk.find(nd, 1))
+                for i, nd in enumerate(needles):
+                    assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (n, limit, wgs, nd)
+    finally:
+        m.set_option("few_max", 32)
+        m.set_option("mid_workgroups", 1024)

@@ -16,8 +16,9 @@ for k, v in (kv.split("=") for kv in os.environ.get("MID_OPTS", "").split(",") i
 reps = int(os.environ.get("MID_REPS", "40"))
 for batch in [int(x) for x in os.environ.get("MID_N", "8 16 17 32 64 128 256").split()]:
     t = []
+    sets = [W.queries(hay, off, batch, 100 + rep) for rep in range(reps + 3)]      # (generated ahead: the calls follow each other)
     for rep in range(reps + 3):
-        q, qo = W.queries(hay, off, batch, 100 + rep)
+        q, qo = sets[rep]
         t0 = time.perf_counter(); rows, counts = m.find_batch_packed(q, qo, limit); dt = time.perf_counter() - t0
         if rep >= 3:
             t.append(dt)

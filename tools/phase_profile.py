@@ -66,7 +66,8 @@ def main():
             print("   manager wave (sweep_role): " + "  ".join(f"{nm_} {v:.0f}" for nm_, v in zip(
                 ["loop", "-", "choose+fetch", "barrier(count)", "-", "settle", "barrier(scan)", "publish"], mg)) + f"  TOTAL {mg.sum():.0f}")
         st = m.find_stats()
-        print(f"   steps/needle {st['steps'] / batch:.1f} postings/needle {st['posting_entries'] / batch:.0f} last_sweep {m.get_option('last_sweep')}")
+        print(f"   steps/needle {st['steps'] / batch:.1f} postings/needle {st['posting_entries'] / batch:.0f} last_sweep {m.get_option('last_sweep')} "
+              f"compactions/needle {st['compactions'] / batch:.2f} resweeps/needle {st['resweeps'] / batch:.2f} tasks/needle {st['tasks'] / batch:.1f}")
         per_needle = tot_all[10:13] / batch
         print(f"   per needle: setup {per_needle[0]:9.0f}  sweeps {per_needle[1]:9.0f}  final compaction + rows {per_needle[2]:9.0f}")
         if tot_all[8]:
