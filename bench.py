@@ -258,7 +258,7 @@ def compact_line(full, detail_path=None):
     if "collective" in full:
         c = full["collective"]
         out["collective"] = _pick(c, ("backend", "world", "rccl_version", "distinct_devices"))
-        out.update(_pick(full, ("gather_ms", "gather_bytes_per_rank", "gather_checked")))
+        out.update(_pick(full, ("gather_ms", "gather_bytes_per_rank", "gather_checked", "shards_verified")))
         out["per_rank_kernel_ms"] = [_r(v, 4) for v in full.get("per_rank", {}).get("kernel_ms", [])]
     if "in_process" in full:
         out["in_process"] = _pick(full["in_process"], ("replicas", "distinct_devices", "peer_access_mask"))
@@ -628,6 +628,33 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             if not torch.equal(gathered[j][0].cpu(), blocks[j].buf.cpu()):
                 raise RuntimeError(f"gathered block {j} differs from the block it was sent from")
             gather_checked += 1
+    # --verify-shards: what rank 0 GATHERED for shard 1 against a direct find of shard 1's needles on rank 0's own replica
+    # (the shards' needles are seeded by rank: rank 0 can generate any of them) -- the one thing `gather_checked` cannot
+    # see: that another rank's block arrives whole and in its slot
+    shards_verified = None
+    if world > 1 and rank == 0 and getattr(args, "verify_shards", False):
+        r = 1
+        if getattr(args, "scaling", "weak") == "strong":
+            from blurrily_amd.sharding import shard_bounds
+            lo_, hi_ = shard_bounds(8 * max(100, int(spec["queries"] * args.scale)), world, r)
+            q2p, q2o = W.queries(hay, hay_off, hi_ - lo_, 4000 + r)
+        else:
+            q2p, q2o = W.bench_needles(hay, hay_off, name, args.scale, r, world)
+        n2 = len(q2o) - 1
+        d2p, d2o = torch.from_numpy(q2p).to(dev), torch.from_numpy(q2o.astype(np.int64)).to(dev)
+        chk = ResultBlock(n2, limit, device=dev)
+        if lib.blurrily_storage_find_batch_device(m.handle, d2p.data_ptr(), int(q2o[-1]), d2o.data_ptr(), n2, limit,
+                                                  chk.rows.data_ptr(), chk.counts.data_ptr(), None, stream) < 0:
+            raise RuntimeError(f"find_batch_device failed: errno {C.get_errno()}")
+        torch.cuda.synchronize()
+        j = (step_no[0] - 1) % len(blocks)
+        got = ResultBlock(n2, limit, buf=gathered[j][r].cpu()) if n2 == n_q else None
+        live = (torch.arange(limit)[None, :] < chk.counts.cpu()[:, None])[:, :, None]
+        same = (got is not None and torch.equal(got.counts, chk.counts.cpu())
+                and torch.equal(torch.where(live, got.rows, 0), torch.where(live, chk.rows.cpu(), 0)))
+        shards_verified = {"shard": r, "needles": int(n2), "equal": bool(same)}
+        if not same:
+            raise RuntimeError(f"rank 0's gathered rows of shard {r} differ from a direct find of the same needles")
     # rows of the LAST TIMED launch, for the parity leg (every launch searches the same batch: both blocks hold them)
     gpu_rows = block.rows.cpu().numpy().view(np.uint32)
     gpu_counts = block.counts.cpu().numpy().view(np.uint32)
@@ -889,6 +916,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             out["gather_bytes_per_rank"] = int(block.buf.numel() * 4)
             out["gather_overlapped"] = True     # gather_ms = what a step saw of the collective (issue + waits)
             out["gather_checked"] = gather_checked
+            out["shards_verified"] = shards_verified
         if not stats_rows_equal:
             log(f"PARITY: the counted launch of '{name}' wrote other rows than the timed one")
             parity_ok = False
@@ -928,6 +956,8 @@ def main():
                     help="N > 1: weak = every rank its own batch of the workload's size (1 M needles per GPU at configs[2]); "
                          "strong = configs[3]'s literal batch, 8 M needles in all at Geonames scale (8 x the workload's), cut "
                          "into N contiguous shards (blurrily_amd/sharding.py: shard_bounds)")
+    ap.add_argument("--verify-shards", action="store_true",
+                    help="N > 1: rank 0 also searches shard 1's needles itself and compares with what it gathered for shard 1")
     ap.add_argument("--in-process", action="store_true",
                     help="--gpus N in ONE process: the image replicated on N devices behind the C ABI (option \"devices\"), "
                          "the N ranks' needles in one call; no torch.distributed")

@@ -1405,7 +1405,7 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     unsigned char* d_rows = O.d_out + which * kOneHostBytes;
     return launch_find_one(a, codes, T, n_rows, per, grid, reinterpret_cast<unsigned long long*>(dp),
                            reinterpret_cast<uint32_t*>(dp + key_bytes), reinterpret_cast<trigram_match_t*>(d_rows),
-                           reinterpret_cast<uint32_t*>(d_rows + kOneWordsAt), seq, O.stream,
+                           reinterpret_cast<uint32_t*>(d_rows + kOneWordsAt), seq, O.stream, uint32_t(m->n_cus),
                            far ? reinterpret_cast<const uint16_t*>(O.d_out + kOneCodesAt) : nullptr,
                            far ? reinterpret_cast<const uint32_t*>(O.d_out + kOneTAt) : nullptr,
                            far ? reinterpret_cast<uint32_t*>(dp + key_bytes + flag_bytes) : nullptr);

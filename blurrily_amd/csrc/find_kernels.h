@@ -155,10 +155,12 @@ constexpr uint32_t kSmallMaxKeep = 64, kSmallMaxWindows = 8;
 // read from host-coherent memory (codes_far [n][64], T_far [n]) and the workgroup that finishes last merges (tickets [n],
 // zero between launches).  T <= 64 distinct trigrams, a.keep <= kOneMaxKeep, grid <= kOneMaxGrid; a.tomb: the select
 // drops deleted references; part_keys [n_needles][grid * keep], flags [n_needles][grid].  Timed build only.
-constexpr uint32_t kOneMaxKeep = 120, kOneMaxGrid = 256, kOneMaxNeedles = 16, kMidMaxNeedles = 128;
+// (kOneMaxGrid: what the merge's scratch -- a window's counters -- holds at kOneMaxKeep; 288 lists let an image of up to 576
+// windows give every workgroup ONE window pair: four times configs[2]'s haystack, 515 windows, 258 workgroups)
+constexpr uint32_t kOneMaxKeep = 120, kOneMaxGrid = 288, kOneMaxNeedles = 16, kMidMaxNeedles = 128;
 int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T, uint32_t n_needles, uint32_t per, uint32_t grid,
                     unsigned long long* part_keys, uint32_t* flags, trigram_match_t* out_rows,
-                    uint32_t* out_count, uint32_t seq, hipStream_t stream, const uint16_t* codes_far = nullptr,
+                    uint32_t* out_count, uint32_t seq, hipStream_t stream, uint32_t n_cus, const uint16_t* codes_far = nullptr,
                     const uint32_t* T_far = nullptr, uint32_t* tickets = nullptr);
 // Window-major sweep of window `w` over needles [0, n) (those with <= 64 distinct trigrams); a.queue must
 // be a zeroed word of its own.  own_pass: only the needles whose own length class lives in this window

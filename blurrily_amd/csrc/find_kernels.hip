@@ -226,19 +226,19 @@ static bool first_launch_on_this_device(std::atomic<uint64_t>& seen) {
   return (seen.fetch_or(bit) & bit) == 0;
 }
 
-template <typename CT, int NT, bool RANGED, bool SHORT, bool LEAVE = false>
+template <typename CT, int NT, bool RANGED, bool SHORT>
 static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   const size_t lds = find_dynamic_lds_bytes(a.pool_cap);
   static std::atomic<uint64_t> attr_done{0};
   if (first_launch_on_this_device(attr_done))
-    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT, LEAVE>),
+    BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_kernel<CT, NT, RANGED, SHORT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024 - int(kWindowSize * sizeof(CT))));   // static counters
-  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT, LEAVE>), dim3(grid), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((find_kernel<CT, NT, RANGED, SHORT>), dim3(grid), dim3(NT), lds, stream, a);
   BLURRILY_HIP_TRY(hipGetLastError());
   char name[64];
-  std::snprintf(name, sizeof name, "find_kernel<%s,%d,%s,%s,%s>", sizeof(CT) == 1 ? "uint8_t" : "uint16_t", NT,
-                RANGED ? "true" : "false", SHORT ? "true" : "false", LEAVE ? "true" : "false");
+  std::snprintf(name, sizeof name, "find_kernel<%s,%d,%s,%s>", sizeof(CT) == 1 ? "uint8_t" : "uint16_t", NT,
+                RANGED ? "true" : "false", SHORT ? "true" : "false");
   ::blurrily::note_launch(name);
   return 0;
 }
@@ -246,15 +246,8 @@ static int launch_find_tr(const FindArgs& a, uint32_t grid, hipStream_t stream) 
 template <typename CT, int NT>
 static int launch_find_t(const FindArgs& a, uint32_t grid, hipStream_t stream) {
   if constexpr (sizeof(CT) == 1) {
-    if (a.short_only) {
-      // (slices can be left out of a step's count: a limit of at most 64 -- the 512-entry pool --, not phase 1 of the
-      // window-major sweep; sweep_role's coop_can_leave asks the same)
-      const bool leave = a.nm_cmin != 0 && a.pool_cap <= 1024 && !a.own_only && find_can_leave(a.keep);
-      if (a.ranges > 1) return leave ? launch_find_tr<CT, NT, true, true, true>(a, grid, stream)
-                                     : launch_find_tr<CT, NT, true, true>(a, grid, stream);
-      return leave ? launch_find_tr<CT, NT, false, true, true>(a, grid, stream)
-                   : launch_find_tr<CT, NT, false, true>(a, grid, stream);
-    }
+    if (a.short_only)                  // (needles of up to 64 trigrams; whether slices are left out: coop_can_leave, at run time)
+      return a.ranges > 1 ? launch_find_tr<CT, NT, true, true>(a, grid, stream) : launch_find_tr<CT, NT, false, true>(a, grid, stream);
   }
   if (a.ranges > 1) return launch_find_tr<CT, NT, true, false>(a, grid, stream);
   return launch_find_tr<CT, NT, false, false>(a, grid, stream);
@@ -303,8 +296,8 @@ int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream) {
 
 int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T, uint32_t n_needles, uint32_t per, uint32_t grid,
                     unsigned long long* part_keys, uint32_t* flags, trigram_match_t* out_rows,
-                    uint32_t* out_count, uint32_t seq, hipStream_t stream, const uint16_t* codes_far, const uint32_t* T_far,
-                    uint32_t* tickets) {
+                    uint32_t* out_count, uint32_t seq, hipStream_t stream, uint32_t n_cus, const uint16_t* codes_far,
+                    const uint32_t* T_far, uint32_t* tickets) {
   OneArgs o;
   const bool far = codes_far != nullptr;               // (the needles' codes are read from host-coherent memory: see OneArgs)
   for (uint32_t i = 0; i < kOneMaxNeedles; ++i) {
@@ -321,7 +314,9 @@ int launch_find_one(const FindArgs& a, const uint16_t* codes, const uint32_t* T,
   if (first_launch_on_this_device(attr_done))
     BLURRILY_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&find_one_kernel<kOneThreads>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(kOneAloneLds)));
-  hipLaunchKernelGGL((find_one_kernel<kOneThreads>), dim3(grid, n_needles), dim3(kOneThreads), n_needles == 1 ? kOneAloneLds : 0, stream, a, o);
+  // (... as long as there is a CU for each: an image of more window pairs than CUs lets two share one rather than wait)
+  const bool alone = n_needles == 1 && grid <= n_cus;
+  hipLaunchKernelGGL((find_one_kernel<kOneThreads>), dim3(grid, n_needles), dim3(kOneThreads), alone ? kOneAloneLds : 0, stream, a, o);
   BLURRILY_HIP_TRY(hipGetLastError());
   ::blurrily::note_launch("find_one_kernel<1024>");
   return 0;

@@ -232,7 +232,7 @@ def test_bench_two_ranks_strong_scaling_plumbing():
     env = dict(os.environ, BLURRILY_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--scale", "0.02", "--scaling", "strong",
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--scale", "0.02", "--scaling", "strong", "--verify-shards",
            "--detail", f"/tmp/blurrily_strong_detail_{os.getpid()}.json"]
     res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -250,6 +250,8 @@ def test_bench_two_ranks_strong_scaling_plumbing():
     assert d["scaling"] == "strong" and d["replicas"] == 2 and d["config"]["needles_per_gpu"] == total // 2
     assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert abs(short["value"] - d["value"]) / d["value"] < 1e-3
+    # what rank 0 gathered for shard 1 equals a direct find of shard 1's needles (--verify-shards)
+    assert short["shards_verified"] == {"shard": 1, "needles": total // 2, "equal": True}
 
 
 def test_bench_n1_under_the_launcher_is_the_plain_n1_line():

@@ -50,7 +50,7 @@ def blocks_of(text, name_part):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    part = args[0] if args else "find_kernelIhLi1024ELb0ELb1"
+    part = args[0] if args else "find_kernelIhLi1024ELb0ELb1E"
     path = args[1] if len(args) > 1 else "blurrily_amd/csrc/find_kernels.gfx950.s"
     name, blocks = blocks_of(open(path).read(), part)
     print(name)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scratch loads / stores of a kernel in `make asm` output with the loop depth of their block.  python tools/asm_scratch_depth.py [kernel substring]"""
 import re, sys
-part = sys.argv[1] if len(sys.argv) > 1 else "find_kernelIhLi1024ELb0ELb1ELb1"
+part = sys.argv[1] if len(sys.argv) > 1 else "find_kernelIhLi1024ELb0ELb1E"
 txt = open("blurrily_amd/csrc/find_kernels.gfx950.s").read()
 m = re.search(r"^(\S*%s\S*):\s" % re.escape(part), txt, flags=re.M)
 start = m.start(); end = txt.index(".Lfunc_end", start)

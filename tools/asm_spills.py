@@ -4,7 +4,7 @@ marks that place the block (barriers, LDS atomics, global loads).  python tools/
 import re
 import sys
 
-part = sys.argv[1] if len(sys.argv) > 1 else "find_kernelIhLi1024ELb0ELb1"
+part = sys.argv[1] if len(sys.argv) > 1 else "find_kernelIhLi1024ELb0ELb1E"
 path = sys.argv[2] if len(sys.argv) > 2 else "blurrily_amd/csrc/find_kernels.gfx950.s"
 txt = open(path).read()
 m = re.search(r"^(\S*%s\S*):\s" % re.escape(part), txt, flags=re.M)

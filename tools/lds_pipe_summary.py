@@ -19,7 +19,7 @@ import os
 import sqlite3
 import sys
 
-LEAVE = "find_kernel<unsigned char, 1024, false, true, true>"
+LEAVE = "find_kernel<unsigned char, 1024, false, true>"
 KERNEL = {"geonames": LEAVE, "words": "find_small_kernel", "geonames_x4": LEAVE, "skewed": LEAVE, "geonames_miss": LEAVE}
 
 

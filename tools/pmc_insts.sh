@@ -17,7 +17,7 @@ c = sqlite3.connect(db)
 rows = c.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name").fetchall()
 tot = {}
 for k, n, v, disp in rows:
-    if "find_kernel<unsigned char, 1024, false, true, true>" in k and "counted::" not in k:
+    if "find_kernel<unsigned char, 1024, false, true>" in k and "counted::" not in k:
         tot[n] = tot.get(n, 0) + v; tot["_disp"] = disp
 steps = json.load(open(os.path.join(d, "detail.json")))["roofline"]["counters"]["steps"]
 disp = tot.pop("_disp", 1)

@@ -20,7 +20,7 @@ for k in order:
         v=d[k]; print(f\"{k}  VGPRs {v.get('VGPRs')}  scratch {v.get('scratch')} B/lane  occupancy {v.get('occ')}  SGPR spills {v.get('sgpr_sp')}  VGPR spills {v.get('vgpr_sp')}\")
 "
 make -s -C blurrily_amd/csrc asm 2>&1 | grep -i error
-for k in find_kernelIhLi1024ELb0ELb1ELb1 find_kernelIhLi1024ELb0ELb1ELb0 find_small_kernel find_one_kernel wsweep_kernel; do
+for k in find_kernelIhLi1024ELb0ELb1E find_kernelIhLi1024ELb1ELb1E find_small_kernel find_one_kernel wsweep_kernel; do
   echo; echo "## $k: blocks with scratch accesses"
   python3 tools/asm_spills.py $k | grep -E "scratch \['|totals"
 done
