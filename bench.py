@@ -132,9 +132,9 @@ def bound_label(device_bytes, hbm_frac, pipes):
     if device_bytes > L2_AGGREGATE_BYTES and hbm_frac >= 0.6:
         return "hbm"
     if pipes and not pipes.get("stale", True) and "error" not in pipes:
-        valu, lds = pipes.get("valu_busy_frac") or 0.0, pipes.get("busy_frac") or 0.0
-        if max(valu, lds) >= 0.6:
-            return "valu issue" if valu >= lds else "lds pipe"
+        valu, lds, salu = pipes.get("valu_busy_frac") or 0.0, pipes.get("busy_frac") or 0.0, pipes.get("salu_busy_frac") or 0.0
+        if max(valu, lds, salu) >= 0.6:
+            return "valu issue" if valu >= max(lds, salu) else "scalar issue" if salu >= lds else "lds pipe"
     return "latency chain"
 
 
@@ -199,6 +199,7 @@ def compact_roofline(rf):
     out["postings_read_fraction"] = _r(rf.get("postings_read_fraction"))
     out["kernel"] = rf.get("kernel")
     out["kernel_ms"] = _r(rf.get("kernel_ms"))
+    out["sweep"] = (rf.get("sweep") or "")[:24]
     return out
 
 
@@ -253,6 +254,8 @@ def compact_line(full, detail_path=None):
         out["cpu_baseline"] = compact_cpu_baseline(full["cpu_baseline"])
     if "extra_configs" in full:
         out["extra_configs"] = {k: compact_extra(k, v) for k, v in full["extra_configs"].items()}
+        if full.get("mid_batch"):
+            out["extra_configs"]["mid_batch"] = compact_extra("mid_batch", full["mid_batch"])
         if "geonames_x4" in full["extra_configs"]:
             out["roofline"]["hbm_point"] = "geonames_x4"    # the one image several times the Infinity Cache: HBM bytes
     if "collective" in full:
@@ -767,7 +770,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
     out, parity_ok = None, True
     if rank == 0:
         # p50 single-needle latency through blurrily_storage_find (host buffers, sync per call)
-        p50_us, p99_us, host_rate = None, None, None
+        p50_us, p99_us, host_rate, mid = None, None, None, None
         m.set_timing(False)          # (the HIP-event bracket of the timed steps is not part of a plain find)
         if latency_probes:
             raw = W.unpack(qp, qo[:latency_probes + 1])
@@ -793,6 +796,28 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
                                                    h_rows.ctypes.data, h_counts.ctypes.data) < 0:
                     raise RuntimeError(f"find_batch failed: errno {C.get_errno()}")
                 host_rate = n_q / (time.perf_counter() - t)
+            # batches of the size a front-end's coalescing produces from concurrent FIND lines (lib/blurrily/server.rb:40-46,
+            # command_processor.rb:41-46): host clock around blurrily_storage_find_batch, rows against the timed launch's
+            mid = {}
+            for nb_ in (8, 16, 32, 64, 128):
+                if nb_ > n_q:
+                    continue
+                sub_o = np.ascontiguousarray(qo[:nb_ + 1])
+                m_rows = np.zeros((nb_, max(limit, 1), 3), dtype=np.uint32)
+                m_counts = np.zeros(nb_, dtype=np.uint32)
+                ts = []
+                for rep_ in range(23):
+                    t = time.perf_counter()
+                    if lib.blurrily_storage_find_batch(m.handle, qp.ctypes.data, sub_o.ctypes.data, nb_, limit,
+                                                       m_rows.ctypes.data, m_counts.ctypes.data) < 0:
+                        raise RuntimeError(f"find_batch failed: errno {C.get_errno()}")
+                    if rep_ >= 3:
+                        ts.append(time.perf_counter() - t)
+                live_ = (np.arange(limit)[None, :] < gpu_counts[:nb_, None])[:, :, None]
+                if not (np.array_equal(m_counts, gpu_counts[:nb_]) and
+                        np.array_equal(np.where(live_, m_rows, 0), np.where(live_, gpu_rows[:nb_], 0))):
+                    raise RuntimeError(f"a host-buffer batch of {nb_} needles and the device-resident batch disagree")
+                mid[f"n{nb_}_p50_us"] = float(np.median(ts) * 1e6)
             if not (np.array_equal(h_counts, gpu_counts) and
                     np.array_equal(np.where((np.arange(limit)[None, :] < gpu_counts[:, None])[:, :, None], h_rows, 0),
                                    np.where((np.arange(limit)[None, :] < gpu_counts[:, None])[:, :, None], gpu_rows, 0))):
@@ -821,6 +846,7 @@ def run_workload(name, args, steps, warmup, rank, local_rank, world, dist, cpu_b
             "p99_query_us": p99_us,
             "latency_probes": int(latency_probes),
             "host_buffer_queries_per_sec": host_rate,
+            "mid_batch": mid if latency_probes else None,
             "matched_entries_per_sec": total_entries * steps / elapsed,
             "entries_per_query": sum_nb / n_q,
             "kernel_ms": k_ms,

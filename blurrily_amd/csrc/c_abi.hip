@@ -1181,6 +1181,43 @@ static int find_batch_chunked(trigram_map m, const char* packed, const uint64_t*
   return rc;
 }
 
+// Blurrily::Map#normalize_string (lib/blurrily/map.rb:40-47) for ONE ASCII needle on the host -- normalise_kernel's two
+// passes, byte for byte (kernels/tokenise.inc: downcase; unless some line is [a-z ]+ every byte that is not a-z becomes a
+// space; whitespace runs squeezed, both ends stripped, trailing NULs too): a handful of raw needles is normalised here
+// and shares find_one_kernel's launch instead of paying a copy in, a normalising launch and the batch's way.  `out` holds
+// at least `cap` bytes; returns the normalised length (up to the first NUL: where the tokeniser stops); *high: whether
+// the needle held a byte >= 0x80 (flagged, not guessed: NFKD is the caller's).
+size_t normalise_one(const char* in, size_t cap, char* out, uint32_t* high_out) {
+  bool plain = false, line_ok = true;
+  size_t line_len = 0;
+  uint32_t high = 0;
+  for (size_t k = 0; k < cap; ++k) {
+    unsigned char c = static_cast<unsigned char>(in[k]);
+    high |= c >> 7;
+    if (c == '\n') { plain |= line_ok && line_len > 0; line_ok = true; line_len = 0; continue; }
+    if (c >= 'A' && c <= 'Z') c += 'a' - 'A';
+    line_ok &= (c >= 'a' && c <= 'z') || c == ' ';
+    ++line_len;
+  }
+  plain |= line_ok && line_len > 0;
+  size_t w = 0, keep = 0;
+  bool gap = false;
+  for (size_t k = 0; k < cap; ++k) {
+    unsigned char c = static_cast<unsigned char>(in[k]);
+    if (c >= 'A' && c <= 'Z') c += 'a' - 'A';
+    const bool letter = c >= 'a' && c <= 'z';
+    if (!plain && !letter) c = ' ';
+    if (c == ' ' || (c >= '\t' && c <= '\r')) { gap = true; continue; }
+    if (gap && w > 0) out[w++] = ' ';
+    gap = false;
+    out[w++] = static_cast<char>(c);
+    if (c != 0) keep = w;
+  }
+  if (high_out) *high_out = high;
+  const void* nul = std::memchr(out, 0, keep);
+  return nul ? size_t(static_cast<const char*>(nul) - out) : keep;
+}
+
 // (a handful of needles share one launch: find_few, below)
 constexpr int kOneNotTaken = -2;
 static int find_few(trigram_map m, const char* const* s, const size_t* len, size_t n, uint16_t limit, trigram_match results,
@@ -1191,17 +1228,33 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
 static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                            trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii) {
   if (n == 0) return 0;
-  if (!raw && n <= m->one.few_max) {                  // a handful of needles: ONE launch (find_few; option "few_max")
+  if (n <= m->one.few_max) {                          // a handful of needles: ONE launch (find_few; option "few_max")
     const char* s[kMidMaxNeedles];
     size_t len[kMidMaxNeedles];
-    for (size_t i = 0; i < n; ++i) {
-      s[i] = packed + offsets[i];
-      const size_t cap = size_t(offsets[i + 1] - offsets[i]);
-      const void* nul = std::memchr(s[i], 0, cap);
-      len[i] = nul ? size_t(static_cast<const char*>(nul) - s[i]) : cap;
+    std::vector<char> norm;                             // raw needles: normalised here, as normalise_kernel would
+    bool fits = true;
+    if (raw) {
+      if (offsets[n] - offsets[0] > (1u << 16)) fits = false;      // (a handful of very long needles: the batch's way)
+      else norm.resize(size_t(offsets[n] - offsets[0]) + 1);
     }
-    const int few = find_few(m, s, len, n, limit, results, counts);
-    if (few != kOneNotTaken) return few;
+    for (size_t i = 0; fits && i < n; ++i) {
+      const size_t cap = size_t(offsets[i + 1] - offsets[i]);
+      if (raw) {
+        char* out = norm.data() + (offsets[i] - offsets[0]);
+        uint32_t high = 0;
+        len[i] = normalise_one(packed + offsets[i], cap, out, &high);
+        s[i] = out;
+        if (non_ascii) non_ascii[i] = high;
+      } else {
+        s[i] = packed + offsets[i];
+        const void* nul = std::memchr(s[i], 0, cap);
+        len[i] = nul ? size_t(static_cast<const char*>(nul) - s[i]) : cap;
+      }
+    }
+    if (fits) {
+      const int few = find_few(m, s, len, n, limit, results, counts);
+      if (few != kOneNotTaken) return few;
+    }
   }
   DeviceScope scope(m->dev.device);
   // what the reference's find does first: tokenise, sort the needle's dirty buckets

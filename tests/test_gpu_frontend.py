@@ -99,6 +99,54 @@ def test_coalesced_finds_equal_one_find_per_line(tmp_path):
         srv.stop()
 
 
+def test_sixty_four_clients_every_reply_checked(tmp_path):
+    """Sixty-four connections, each asking one FIND at a time and waiting for its reply (the reference's client,
+    lib/blurrily/client.rb:35-41): what the server coalesces is then a batch of a few dozen needles -- the size that takes
+    find_one_kernel's shared launch (raw needles, normalised by the library on the host) or latency mode's ranges -- and
+    every reply equals what one find per line gives (lib/blurrily/command_processor.rb:41-46)."""
+    hay, off = W.geonames(120000, 9000, seed=29)                # two windows
+    strings = [s.decode() for s in W.unpack(hay, off)]
+    reference = Map()
+    reference.put_many(strings, list(range(1, len(strings) + 1)))
+    srv = _InProcessServer(tmp_path)
+    try:
+        srv.server._map_group.map("places").put_many(strings, list(range(1, len(strings) + 1)))
+        rng = np.random.default_rng(31)
+        per_conn = []
+        for c in range(64):
+            lines = []
+            for _ in range(30):
+                s = strings[int(rng.integers(0, len(strings)))]
+                if rng.random() < 0.3:
+                    s = s[: max(1, len(s) - 2)]
+                limit = int(rng.choice([1, 5, 10, 40]))
+                lines.append(f"FIND\tplaces\t{s.title() if rng.random() < 0.3 else s}\t{limit}")
+            per_conn.append(lines)
+
+        async def one_at_a_time(lines):
+            reader, writer = await asyncio.open_connection("127.0.0.1", srv.port)
+            out = []
+            for line in lines:
+                writer.write((line + "\n").encode())
+                await writer.drain()
+                out.append((await reader.readline()).decode().rstrip("\n"))
+            writer.close()
+            return out
+
+        async def run_all():
+            return await asyncio.gather(*[one_at_a_time(lines) for lines in per_conn])
+
+        replies = asyncio.run(run_all())
+        cp = CommandProcessor(type("G", (), {"map": lambda self, name: reference, "clear": None})())
+        for lines, got in zip(per_conn, replies):
+            assert got == [cp.process_command(line) for line in lines]
+        stats = srv.server.stats
+        assert stats["finds"] == 64 * 30
+        assert 1 < stats["largest_batch"] <= 64, stats           # coalesced, and never more than a needle per client
+    finally:
+        srv.stop()
+
+
 def test_mutations_keep_their_place_between_finds(tmp_path):
     srv = _InProcessServer(tmp_path)
     try:

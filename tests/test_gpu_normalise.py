@@ -132,3 +132,43 @@ def test_map_find_batch_mixes_device_and_host_normalisation():
         m.put(s, i)
     needles = ["LONDON", "São  Paulo", "café de Flore", "New-York", "@€%é"]
     assert m.find_batch(needles, 3) == [m.find(s, 3) for s in needles]
+
+
+def test_a_handful_of_raw_needles_is_normalised_on_the_host_and_shares_one_launch():
+    """blurrily_storage_find_batch_raw with up to "few_max" needles: normalised by the library on the host -- the C++ twin of
+    normalise_kernel -- and served by find_one_kernel's launch (c_abi.hip: normalise_one, find_few): same rows and flags as
+    the device's normalisation gives the same needles in a larger batch, and as finds over host-normalised needles."""
+    rng = np.random.default_rng(77)
+    hay, off = W.geonames(60000, 8000, seed=5)
+    strings = W.unpack(hay, off)
+    m = RawMap()
+    m.put_many_packed(hay, off, np.arange(1, len(strings) + 1, dtype=np.uint32))
+    alphabet = list(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOP0123456789 \t\n\r\x0b\x0c.,;-'!?\x00\x7f")
+    raw = []
+    for k in range(400):
+        t = bytearray(strings[int(rng.integers(0, len(strings)))])
+        for _ in range(int(rng.integers(0, 5))):
+            pos = int(rng.integers(0, len(t) + 1))
+            t[pos:pos] = bytes([alphabet[int(rng.integers(0, len(alphabet)))]])
+        if k % 7 == 0:
+            t = bytearray(bytes(t).upper())
+        raw.append(bytes(t))
+    raw += [b"", b"  ", b"!!!", b"Two\nLines", b"a\x00b", b"\x00", b"x  y", b"caf\xc3\xa9"]
+    big_p, big_o = _pack(raw)
+    want_rows, want_counts, want_flags = m.find_batch_raw_packed(big_p, big_o, 10)       # (408 needles: the device normalises)
+    assert m.get_option("few_max") == 32
+    taken = m.get_option("one_taken")
+    for lo in range(0, len(raw), 17):                                                  # batches of 17 (and a shorter last one)
+        part = raw[lo:lo + 17]
+        p_, o_ = _pack(part)
+        rows, counts, flags = m.find_batch_raw_packed(p_, o_, 10)
+        assert np.array_equal(counts, want_counts[lo:lo + len(part)]) and np.array_equal(flags, want_flags[lo:lo + len(part)])
+        for i in range(len(part)):
+            assert np.array_equal(rows[i, :counts[i]], want_rows[lo + i, :counts[i]]), part[i]
+    assert m.get_option("one_taken") > taken                                           # ... through the shared launch
+    # and the single raw needle
+    for i in (0, 5, len(raw) - 5, len(raw) - 1):
+        p_, o_ = _pack([raw[i]])
+        rows, counts, flags = m.find_batch_raw_packed(p_, o_, 10)
+        assert counts[0] == want_counts[i] and np.array_equal(rows[0, :counts[0]], want_rows[i, :counts[0]]) and flags[0] == want_flags[i]
+    m.close()

@@ -13,15 +13,15 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python $root/bench.py > $out/bench.json 2> $out/bench.log
+python $root/bench.py --detail $out/bench_detail.json > $out/bench.json 2> $out/bench.log   # (bench.json: the short line; bench_detail.json: the record)
 # (--latency-probes 0: no single finds, no host-buffer batch -- whose chunks are launches of the same kernel --
 #  so that the kernel's average duration in the summary is the timed steps' and the warm-up's)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra --latency-probes 0 > $out/stats_bench.json 2> $out/stats_bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline --latency-probes 0 > $out/stats_skewed.json 2> $out/stats_skewed.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x4 -o bench -- python $root/bench.py --workload geonames_x4 --no-cpu-baseline --latency-probes 0 > $out/stats_x4.json 2> $out/stats_x4.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_words -o bench -- python $root/bench.py --workload words --no-cpu-baseline --latency-probes 0 > $out/stats_words.json 2> $out/stats_words.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra --latency-probes 0 --detail $out/stats_bench_detail.json > $out/stats_bench.json 2> $out/stats_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline --latency-probes 0 --detail $out/stats_skewed_detail.json > $out/stats_skewed.json 2> $out/stats_skewed.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x4 -o bench -- python $root/bench.py --workload geonames_x4 --no-cpu-baseline --latency-probes 0 --detail $out/stats_x4_detail.json > $out/stats_x4.json 2> $out/stats_x4.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_words -o bench -- python $root/bench.py --workload words --no-cpu-baseline --latency-probes 0 --detail $out/stats_words_detail.json > $out/stats_words.json 2> $out/stats_words.log
 # the sweep the bench run above took for a workload (its measured choice): the PMC passes force the same one
-sweep_of() { python - "$out/bench.json" "$1" <<'PY'
+sweep_of() { python - "$out/bench_detail.json" "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); wl = sys.argv[2]
 r = (d if wl == "geonames" else d["extra_configs"][wl])["roofline"]["sweep"]
@@ -34,7 +34,7 @@ for wl in geonames words skewed geonames_x4 geonames_miss; do
     name=${pass%%:*}; ctrs=${pass#*:}
     d=$out/pmc_${name}_$wl
     mkdir -p $d
-    rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $wl --steps 1 --warmup 0 --force-sweep ${fs:-0} --no-cpu-baseline --latency-probes 0 > $d/bench.json 2> $d/bench.log
+    rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $wl --steps 1 --warmup 0 --force-sweep ${fs:-0} --no-cpu-baseline --latency-probes 0 --detail $d/detail.json > $d/bench.json 2> $d/bench.log
   done
 done
 python $root/tools/traffic_summary.py $out > $out/traffic.json

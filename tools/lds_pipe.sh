@@ -17,7 +17,7 @@ for wl in "geonames:3" "words:4" "geonames_x4:3" "skewed:3" "geonames_miss:3"; d
     p=${pass%%:*}; ctrs=${pass#*:}
     d=$out/pmc_${p}_$name
     mkdir -p $d
-    timeout 300 rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $name --steps 1 --warmup 0 --force-sweep $fs --no-cpu-baseline --no-extra --latency-probes 0 > $d/bench.json 2> $d/bench.log
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-trace -d $d -o pmc -- python $root/bench.py --workload $name --steps 1 --warmup 0 --force-sweep $fs --no-cpu-baseline --no-extra --latency-probes 0 --detail $d/detail.json > $d/bench.json 2> $d/bench.log
   done
 done
 python $root/tools/lds_pipe_summary.py $out > $out/lds_pipe.json

@@ -66,7 +66,7 @@ def main():
         if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES"):
             d["wait_any_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
         try:
-            line = json.loads(open(os.path.join(base, f"pmc_idx_{wl}", "bench.json")).read().strip().splitlines()[-1])
+            line = json.load(open(os.path.join(base, f"pmc_idx_{wl}", "detail.json")))      # (bench.py --detail: the full record)
             d["kernel_ms_under_pmc"] = line.get("kernel_ms")
             d["sweep"] = line.get("roofline", {}).get("sweep")
         except Exception:
