@@ -159,6 +159,7 @@ struct trigram_map_t {
   hipEvent_t  watch_ev[8][2] = {};
   bool        watch_pending[8] = {false, false, false, false, false, false, false, false};
   size_t      watch_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t      tuned_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // the batch size a class was measured at (the watch compares like with like)
   float       tuned_us_per_needle[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // of the sweep that was chosen
   uint32_t    retune_holdoff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t    watch_strikes[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // consecutive batches of the class seen slow (one is noise: another tenant, a clock step)
@@ -562,7 +563,10 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       if (tunable && !cb && m->watch_pending[cls] && hipEventQuery(m->watch_ev[cls][1]) == hipSuccess) {
         float ms = 0.f;
         m->watch_pending[cls] = false;
-        if (hipEventElapsedTime(&ms, m->watch_ev[cls][0], m->watch_ev[cls][1]) == hipSuccess && m->watch_n[cls] &&
+        // (only a batch of about the size the class was measured at is held against that figure: classes 6 / 7 span 129 ..
+        // 16 383 needles, and a small batch's fixed costs -- 1.4 us a needle at 256 against 0.5 at 4 096 -- are not a slow sweep)
+        const bool comparable = m->tuned_n[cls] != 0 && m->watch_n[cls] * 2 >= m->tuned_n[cls] && m->watch_n[cls] <= m->tuned_n[cls] * 2;
+        if (hipEventElapsedTime(&ms, m->watch_ev[cls][0], m->watch_ev[cls][1]) == hipSuccess && m->watch_n[cls] && comparable &&
             m->tuned_us_per_needle[cls] > 0.f && m->ws_choice[cls] != 0) {
           const float us = 1000.f * ms / float(m->watch_n[cls]);
           // (TWO batches in a row: a single slow one -- seen on a shared box, 2.3 x inside bench.py's three timed steps --
@@ -620,6 +624,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
         m->ws_choice[cls] = choice;
         m->ws_tuned_ms[cls][0] = ms_of[1]; m->ws_tuned_ms[cls][1] = ms_of[2]; m->ws_tuned_ms[cls][2] = ms_of[3];
         m->tuned_us_per_needle[cls] = 1000.f * best / float(n);
+        m->tuned_n[cls] = n;
         m->watch_pending[cls] = false;
         m->last_tuned = cls;
         m->last_sweep = 1;                             // (the rows in place are the plain run's; all give the same)
@@ -628,8 +633,15 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
       }
       const bool watch = tunable && !cb && m->ws_choice[cls] == choice && m->tuned_us_per_needle[cls] > 0.f;
       if (watch) {
-        if (!m->watch_ev[cls][0])
-          for (auto& e : m->watch_ev[cls]) BLURRILY_HIP_TRY(hipEventCreate(&e));
+        if (!m->watch_ev[cls][1]) {                    // (both events or none: a half-made pair would be recorded into)
+          hipEvent_t e0 = nullptr, e1 = nullptr;
+          if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            errno = EIO;
+            return -1;
+          }
+          m->watch_ev[cls][0] = e0; m->watch_ev[cls][1] = e1;
+        }
         BLURRILY_HIP_TRY(hipEventRecord(m->watch_ev[cls][0], stream));
       }
       if (run_sweep(choice) < 0) return -1;
