@@ -15,10 +15,12 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python $root/bench.py --detail $out/bench_detail.json > $out/bench.json 2> $out/bench.log   # (bench.json: the short line; bench_detail.json: the record)
 # (--latency-probes 0: no single finds, no host-buffer batch -- whose chunks are launches of the same kernel --
-#  so that the kernel's average duration in the summary is the timed steps' and the warm-up's)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --no-cpu-baseline --no-extra --latency-probes 0 --detail $out/stats_bench_detail.json > $out/stats_bench.json 2> $out/stats_bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --no-cpu-baseline --latency-probes 0 --detail $out/stats_skewed_detail.json > $out/stats_skewed.json 2> $out/stats_skewed.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x4 -o bench -- python $root/bench.py --workload geonames_x4 --no-cpu-baseline --latency-probes 0 --detail $out/stats_x4_detail.json > $out/stats_x4.json 2> $out/stats_x4.log
+#  so that the kernel's average duration in the summary is the timed steps' and the warm-up's; --force-sweep 3: the sweep
+#  the bench run's measurement picks, without the measurement -- since round 6 the plain sweep and the one that leaves
+#  slices out are ONE kernel symbol, and the measurement's plain runs would be averaged in)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $root/bench.py --force-sweep 3 --no-cpu-baseline --no-extra --latency-probes 0 --detail $out/stats_bench_detail.json > $out/stats_bench.json 2> $out/stats_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_skewed -o bench -- python $root/bench.py --workload skewed --force-sweep 3 --no-cpu-baseline --latency-probes 0 --detail $out/stats_skewed_detail.json > $out/stats_skewed.json 2> $out/stats_skewed.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x4 -o bench -- python $root/bench.py --workload geonames_x4 --force-sweep 3 --no-cpu-baseline --latency-probes 0 --detail $out/stats_x4_detail.json > $out/stats_x4.json 2> $out/stats_x4.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_words -o bench -- python $root/bench.py --workload words --no-cpu-baseline --latency-probes 0 --detail $out/stats_words_detail.json > $out/stats_words.json 2> $out/stats_words.log
 # the sweep the bench run above took for a workload (its measured choice): the PMC passes force the same one
 sweep_of() { python - "$out/bench_detail.json" "$1" <<'PY'
