@@ -274,7 +274,7 @@ size_t blurrily_storage_last_kernels(trigram_map haystack, char* out, size_t cap
  *                             the count -- at most need - nm_cmin of them, eight at most -- and settle the candidates
  *                             that leaves pending through the slices' bitmaps; 0: never.  Limits up to 149 (the candidate pool's tail
  *                             has to hold the settled candidates beside what a glance at the pool lets pass)
- *   "nm_dense"        (4096)  ... slices of at least this many postings only (not below "dense_min")
+ *   "nm_dense"        (3072)  ... slices of at least this many postings only (not below "dense_min")
  *   "nm_min_windows"  (256)   ... and, where the choice is not measured, on images of at least this many windows
  *   "small_sweep"     (1)     an image of at most eight windows serves batches of at least "small_min_needles" (4096)
  *                             needles at limits up to 64 with four waves and one window's counters per needle -- four

@@ -84,7 +84,7 @@ def test_options_set_and_get():
     m = RawMap()
     defaults = {"wsweep": 1, "ws_cmin": 3, "ws_min_windows": 8, "ws_min_needles": 16384, "dense_min": 1024,
                 "ws_min_slice": 1550, "ws_autotune": 1, "ws_static_slice": 2200, "ws_choice": 0, "host_chunk": 131072,
-                "nm_cmin": 3, "nm_dense": 4096, "nm_min_windows": 256, "devices": 1, "last_sweep": 0, "small_sweep": 1,
+                "nm_cmin": 3, "nm_dense": 3072, "nm_min_windows": 256, "devices": 1, "last_sweep": 0, "small_sweep": 1,
                 "small_min_needles": 4096}
     for k, v in defaults.items():
         assert m.get_option(k) == v, k

@@ -1,0 +1,1 @@
+EDITS = [("kernels/needle_major.inc", "constexpr uint32_t kNmMaxLeftOut = 8;", "constexpr uint32_t kNmMaxLeftOut = 4;")]
