@@ -1358,7 +1358,7 @@ static int find_batch_host(trigram_map m, const char* packed, const uint64_t* of
 // The reference's only call shape (ext/blurrily/map_ext.c:131-162 -> storage.c:477-580), and small host-buffer batches
 // (a server's coalesced FINDs under light load).  needle i = s[i][0 .. len[i]) (up to its first NUL).  Returns 0 with
 // counts[] and rows filled (results + i * limit), -1 with errno, or kOneNotTaken when the finds have to go the batch's
-// way: a limit of 0 or above kOneMaxKeep, more than kOneMaxNeedles needles, a needle of more than 64 distinct trigrams,
+// way: a limit of 0 or above kOneMaxKeep, more than kMidMaxNeedles needles, a needle of more than 64 distinct trigrams,
 // timing or request counters switched on, option "one_launch" 0.  Mutations the base image does not hold yet are
 // served: tombstones inside the select, pending puts by a second launch over the delta image.
 constexpr size_t kOneRowBytes = kOneMaxKeep * sizeof(trigram_match_t);
