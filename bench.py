@@ -83,7 +83,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (imported before the HIP library so both share one HIP runtime)
 
 PARITY_FLOOR = 64              # needles of every benched config compared row for row with the reference in the run
-PARITY_WORKERS = 16            # ... the ones beyond the timed sample on forked readers of the same read-only file
+PARITY_WORKERS = 16            # ... the ones beyond the timed sample on readers in processes of their own (tools/ref_reader.py) over the same read-only file
 INFINITY_CACHE_BYTES = 256 << 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0    # the same guide: 6.29 TB/s measured (float4 copy, 79 % of the spec)
@@ -357,31 +357,43 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s, gpu_rows, gpu_counts)
     k = min(4, len(raw))
     per = run(0, k) / k
     # TIMED on one core: what the budget buys (a handful of needles at least).  COMPARED: at least PARITY_FLOOR needles
-    # whatever the budget -- the ones beyond the timed sample are answered by forked readers of the same read-only
+    # whatever the budget -- the ones beyond the timed sample are answered by readers in processes of their own over the same read-only
     # file (their time is nobody's figure), so that a haystack on which the reference takes a second per needle still
     # gets its 64 rows-for-rows without a minute of serial CPU
     n = int(max(min(4, len(raw)), min(len(raw), budget_s / max(per, 1e-7))))
     dt = run(0, n)
     n_timed = n
     want = min(max(PARITY_FLOOR, n), len(raw))
-    if want > n:
-        if kind == "reference" and hasattr(os, "fork"):
-            import multiprocessing as mp
-            ctx = mp.get_context("fork")
-            qres = ctx.Queue()
-            bounds = np.linspace(n, want, min(PARITY_WORKERS, want - n) + 1).astype(int)
+    # (readers in processes of their own -- tools/ref_reader.py, started fresh: a process with HIP and torch initialised
+    # is not one to fork -- over the same read-only file)
+    import subprocess, tempfile
+    tmpd = tempfile.mkdtemp(prefix="blurrily_bench_")
+    needles_npz = os.path.join(tmpd, "needles.npz")
 
-            def reader(lo, hi):
-                run(lo, hi)
-                qres.put((lo, hi, rows[lo:hi].copy(), counts[lo:hi].copy()))
-            procs = [ctx.Process(target=reader, args=(int(a), int(b))) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
-            for p_ in procs:
-                p_.start()
-            for _ in procs:
-                lo, hi, r_, c_ = qres.get(timeout=600)
+    def readers(spans):
+        """run tools/ref_reader.py over [lo, hi) spans concurrently; returns [(lo, hi, rows, counts, t0, t1)]"""
+        if not os.path.exists(needles_npz):
+            np.savez(needles_npz, packed=packed, starts=starts)
+        procs = []
+        for k_, (lo, hi) in enumerate(spans):
+            out_ = os.path.join(tmpd, f"out_{k_}.npz")
+            procs.append((lo, hi, out_, subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "ref_reader.py"), path, needles_npz,
+                                                          str(lo), str(hi), str(limit), out_], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+        got = []
+        for lo, hi, out_, p_ in procs:
+            _, err_ = p_.communicate(timeout=900)
+            if p_.returncode != 0:
+                raise RuntimeError(f"ref_reader failed: {err_.decode()[-300:]}")
+            z = np.load(out_)
+            got.append((lo, hi, z["rows"], z["counts"], float(z["span"][0]), float(z["span"][1])))
+            os.unlink(out_)
+        return got
+
+    if want > n:
+        if kind == "reference":
+            bounds = np.linspace(n, want, min(PARITY_WORKERS, want - n) + 1).astype(int)
+            for lo, hi, r_, c_, _, _ in readers([(int(a_), int(b_)) for a_, b_ in zip(bounds[:-1], bounds[1:]) if b_ > a_]):
                 rows[lo:hi] = r_; counts[lo:hi] = c_
-            for p_ in procs:
-                p_.join()
         else:
             run(n, want)
         n = want
@@ -400,33 +412,21 @@ def cpu_baseline(m, hay, hay_off, qp, qo, limit, budget_s, gpu_rows, gpu_counts)
         i = mismatches[0]
         log(f"PARITY MISMATCH at needle {i} {raw[i]!r}: cpu {rows[i, :int(counts[i])].tolist()} "
             f"gpu {gpu_rows[i, :int(gpu_counts[i])].tolist()}")
-    # The reference is single-threaded; for scale, the same read-only map queried by one forked
+    # The reference is single-threaded; for scale, the same read-only map queried by one reader
     # process per host core (each maps the same file), every process timing the same needles.
-    if kind == "reference" and hasattr(os, "fork") and budget_s >= 10:
+    if kind == "reference" and budget_s >= 10:
         try:
             cores = min(os.cpu_count() or 1, 128)
-            import multiprocessing as mp
-            ctx = mp.get_context("fork")
-            q = ctx.Queue()
-
             n_all = max(2, n_timed // 10)        # memory-bound when every core runs: keep it short
-
-            def worker(i):
-                t0 = time.perf_counter()
-                run(0, n_all)
-                q.put((t0, time.perf_counter()))
-            procs = [ctx.Process(target=worker, args=(i,)) for i in range(cores)]
-            for p_ in procs:
-                p_.start()
-            spans = [q.get(timeout=300) for _ in procs]
-            for p_ in procs:
-                p_.join()
-            wall = max(e for _, e in spans) - min(b for b, _ in spans)
+            spans = readers([(0, n_all)] * cores)
+            wall = max(e for *_, e in spans) - min(b_ for *_, b_, _ in spans)
             out["all_cores"] = {"value": cores * n_all / wall, "unit": "queries/s", "cores": cores,
                                 "note": f"one process per hardware thread on the shared read-only map, "
                                         f"{n_all} needles each"}
         except Exception as e:                       # informational only
             out["all_cores"] = {"error": str(e)}
+    import shutil
+    shutil.rmtree(tmpd, ignore_errors=True)
     done()
     return out
 
