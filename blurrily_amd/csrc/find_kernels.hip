@@ -128,6 +128,7 @@ constexpr uint32_t kPadPair   = uint32_t(kPadRank) | (uint32_t(kPadRank) << 16);
 // counted build -- find_kernels_counted.hip -- compiles all of it once more in namespace blurrily::counted):
 #include "kernels/tokenise.inc"
 #include "kernels/counters.inc"
+#include "kernels/pipelined.inc"
 #include "kernels/needle_major.inc"
 #include "kernels/merge.inc"
 #include "kernels/window_major.inc"
