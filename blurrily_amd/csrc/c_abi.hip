@@ -77,8 +77,13 @@ struct PendingPut {
 
 struct trigram_map_t;
 namespace {
-// where note_launch() writes: the `last_kernels` of the map whose batch is being enqueued on this thread (run_find_on)
+// where note_launch() writes: the `last_kernels` of the map whose batch is being enqueued on this thread (run_find_on, find_few)
 thread_local std::string* t_launch_names = nullptr;
+struct NameScope {                                     // the launches inside it note their kernels' names in *s
+  std::string* prev;
+  explicit NameScope(std::string* s) : prev(t_launch_names) { t_launch_names = s; }
+  ~NameScope() { t_launch_names = prev; }
+};
 }
 namespace blurrily {
 void note_launch(const char* kernel_name) {
@@ -188,8 +193,10 @@ struct trigram_map_t {
     bool           enabled = true;      // option "one_launch"
     uint32_t       min_per = 0;         // option "one_windows_per_wg": at least this many windows per workgroup (0: as few as the grid allows)
     uint32_t       mid_workgroups = 1024;   // option "mid_workgroups": workgroups a launch of more than kOneMaxNeedles needles aims at
-    uint32_t       few_max = 32;        // option "few_max": host-buffer batches of up to this many needles share find_one_kernel's launch
-                                        // (up to kMidMaxNeedles; from about forty needles on latency mode's ranges are faster: DESIGN.md)
+    uint32_t       few_max = 24;        // option "few_max": host-buffer batches of up to this many needles share find_one_kernel's launch
+                                        // (up to kMidMaxNeedles; from about thirty needles on latency mode's ranges are faster: DESIGN.md)
+    uint32_t       mid_max = kMidMaxNeedles;   // option "mid_max": ... and up to this many take latency mode WITHOUT copies: tokenised on the
+                                        // host, read from the pinned page, the merged rows written back into it (find_few)
     uint64_t       taken = 0;           // finds served this way (option "one_taken", read-only)
   } one;
   // large host-buffer batches go in chunks through a three-stream pipeline (find_batch_chunked)
@@ -321,6 +328,20 @@ constexpr size_t kPhaseWorkgroups = 8192, kPhaseBytes = kPhaseWorkgroups * 16 * 
 constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for small host-buffer batches
 
 // the timed build of the kernels, or (while request counters are collected) the counted one
+// Latency mode: the ranges a needle's windows are cut into when n needles are too few to fill `wgs` resident workgroups
+// (1: whole needles).  Tasks aimed at: ONE per workgroup up to about fifty needles -- every task starts at once, none
+// queues behind another's learning sweep --, two beyond (round 6, tools/experiments/r6_run_lt.sh, host clock at Geonames
+// scale, one / two / four tasks per workgroup: 32 needles 146 / 168 / 223 us, 48: 197 / 226 / 282, 64: 230 / 226 / 275,
+// 128: 324 / 275 / 306; through round 5 two, and four from a hundred needles on); from about one needle per FOUR
+// workgroups whole needles win (through round 4: per workgroup -- the whole-needle sweeps have become faster since, the
+// ranged one pays its learning sweep and merge: at Geonames scale 256 needles 503 -> 366 us, 512: 737 -> 617).
+uint32_t latency_ranges(size_t n, uint32_t limit, uint32_t n_windows, size_t wgs) {
+  if (limit == 0 || limit > 1024 || n * 4 > wgs || n_windows <= 2) return 1;
+  const size_t target_tasks = (n < 56 ? 1 : 2) * wgs;
+  uint32_t ranges = uint32_t(std::min<size_t>((n_windows + 1) / 2, target_tasks / n));   // ranges are whole window pairs
+  return std::max<uint32_t>(1u, std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit)));      // (the merge's pool)
+}
+
 int do_launch_find(bool counted_build, const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream) {
   return counted_build ? counted::launch_find(a, long_needles, grid, stream) : launch_find(a, long_needles, grid, stream);
 }
@@ -334,11 +355,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
   if (n > 0xFFFFFFF0ull) { errno = EINVAL; return -1; }
   const bool is_base = &ix == &m->dev;                 // (the delta image of pending puts is searched the same way)
   if (is_base) m->last_sweep = 0;
-  struct NameScope {                                   // the launches below note their kernels' names in the map
-    std::string* prev;
-    explicit NameScope(std::string* s) : prev(t_launch_names) { t_launch_names = s; }
-    ~NameScope() { t_launch_names = prev; }
-  } name_scope(is_base ? &m->last_kernels : nullptr);
+  NameScope name_scope(is_base ? &m->last_kernels : nullptr);    // the launches below note their kernels' names in the map
   if (is_base) m->last_kernels.clear();
 
   // scratch: codes | per-needle arrays | scalars
@@ -412,16 +429,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // Latency mode: a batch too small to fill the GPU cuts every needle's windows into ranges
     // swept by different workgroups, then merges the per-range candidates (single pass only).
     const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
-    uint32_t ranges = 1;
-    // Tasks aimed at: two per workgroup for a handful of needles, four from a hundred needles on
-    // (measured, tools/batch_sweep.py); from about one needle per FOUR workgroups whole needles win (through round 4:
-    // per workgroup -- the whole-needle sweeps have become faster since, the ranged one pays its learning sweep and
-    // merge: at Geonames scale 256 needles 503 -> 366 us, 512: 737 -> 617).
-    const size_t target_tasks = (n <= 96 ? 2 : 4) * wgs;
-    if (limit <= 1024 && n * 4 <= wgs && ix.n_windows > 2) {
-      ranges = uint32_t(std::min<size_t>((ix.n_windows + 1) / 2, target_tasks / n));   // ranges are whole window pairs
-      ranges = std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit));     // merge pool
-    }
+    const uint32_t ranges = latency_ranges(n, limit, ix.n_windows, wgs);
     if (ranges > 1) {
       const size_t tasks = n * ranges;
       const size_t key_bytes = align_up(tasks * limit * 8, 256);
@@ -1241,7 +1249,7 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
 static int find_batch_host(trigram_map m, const char* packed, const uint64_t* offsets, size_t n, uint16_t limit,
                            trigram_match results, uint32_t* counts, bool raw, uint32_t* non_ascii) {
   if (n == 0) return 0;
-  if (n <= m->one.few_max) {                          // a handful of needles: ONE launch (find_few; option "few_max")
+  if (n <= std::max(m->one.few_max, m->one.mid_max)) { // a handful of needles: no copies (find_few; options "few_max", "mid_max")
     const char* s[kMidMaxNeedles];
     size_t len[kMidMaxNeedles];
     std::vector<char> norm;                             // raw needles: normalised here, as normalise_kernel would
@@ -1366,7 +1374,11 @@ constexpr size_t kOneRowBytes = kOneMaxKeep * sizeof(trigram_match_t);
 constexpr size_t kOneWordsAt = kMidMaxNeedles * kOneRowBytes;
 constexpr size_t kOneCodesAt = kOneWordsAt + kMidMaxNeedles * 8 + 64;
 constexpr size_t kOneTAt = kOneCodesAt + kMidMaxNeedles * 64 * sizeof(uint16_t);
-constexpr size_t kOneHostBytes = kOneTAt + kMidMaxNeedles * sizeof(uint32_t) + 64;
+// ... | postings [kMidMaxNeedles] | start window [kMidMaxNeedles] | code offsets [kMidMaxNeedles + 1] (latency mode's needle arrays)
+constexpr size_t kMidNbAt = kOneTAt + kMidMaxNeedles * sizeof(uint32_t);
+constexpr size_t kMidStartAt = kMidNbAt + kMidMaxNeedles * sizeof(uint32_t);
+constexpr size_t kMidOffAt = (kMidStartAt + kMidMaxNeedles * sizeof(uint32_t) + 7) & ~size_t(7);
+constexpr size_t kOneHostBytes = kMidOffAt + (kMidMaxNeedles + 1) * sizeof(uint64_t) + 64;
 // lists a launch may leave: up to sixteen rows of kOneMaxGrid workgroups, or more rows of fewer (find_few aims at a
 // thousand workgroups in all)
 constexpr size_t kOneMaxLists = size_t(kOneMaxNeedles) * kOneMaxGrid;
@@ -1398,17 +1410,20 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   // merged here (they hold disjoint references).  A log that has overflowed is folded by ensure_device above.
   const bool with_tomb = log_of(m)->n_tomb != 0, with_delta = !log_of(m)->pending.empty() && m->delta.device >= 0;
   // needles without a posting return no rows (storage.c:503) and take no row of the grid
-  uint32_t row_of[kMidMaxNeedles], n_rows = 0;
+  uint32_t row_of[kMidMaxNeedles], row_nb[kMidMaxNeedles], n_rows = 0;
   for (size_t i = 0; i < n; ++i) {
     uint64_t nb = 0;
     for (uint32_t k = 0; k < T[i]; ++k) nb += m->host->bucket(codes[i * 64 + k]).used;
     counts[i] = 0;
     if (nb == 0) continue;
     if (n_rows != i) { std::memmove(codes + n_rows * 64, codes + i * 64, 64 * sizeof(uint16_t)); T[n_rows] = T[i]; }
+    row_nb[n_rows] = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(nb);
     row_of[n_rows++] = uint32_t(i);
   }
   if (n_rows == 0) return 0;
   auto& O = m->one;
+  NameScope name_scope(&m->last_kernels);                 // (the launches below note their kernels' names in the map)
+  m->last_kernels.clear();
   if (!O.h_out) {
     // stream, pinned page and its device address: built in locals and kept only when ALL of them exist (a half-made set
     // -- a stream without its page -- would have the next find skip this block and poll a null page)
@@ -1428,15 +1443,38 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     O.stream = st; O.h_out = h; O.d_out = d;
   }
   if (with_tomb && apply_tombstones(m, O.stream) < 0) return -1;       // (deletes since the last find: their bits are set first)
-  const size_t key_bytes = kOneMaxLists * kOneMaxKeep * 8, flag_bytes = kOneMaxLists * 4, ticket_bytes = kMidMaxNeedles * 4;
+  const size_t key_bytes = kOneMaxLists * kOneMaxKeep * 8, flag_bytes = kOneMaxLists * 4, ticket_bytes = (kMidMaxNeedles + 1) * 4;   // (+ latency mode's queue word)
   const size_t part_bytes = key_bytes + flag_bytes + ticket_bytes;
   if (!O.d_parts.p) {
     if (O.d_parts.reserve(2 * part_bytes, O.stream) < 0) return -1;
     BLURRILY_HIP_TRY(hipMemsetAsync(O.d_parts.p, 0, 2 * part_bytes, O.stream));
   }
-  // more than kOneMaxNeedles rows: the codes travel in the pinned page (both images' launches read the first image's copy)
+  // More than few_max rows: the BASE image is searched in latency mode -- find_kernel<..., RANGED>, a needle's windows cut
+  // into ranges, a task per workgroup: beyond about thirty needles its pipelined steps beat find_one_kernel's exact
+  // selects -- but without the batch path's copies: the per-needle arrays its tokeniser would have left
+  // on the device (trigram counts, postings, the window of the needle's own length class, where its codes start) are
+  // written here, into the pinned page, and read over the link by the tasks; the merge writes rows, counts and
+  // sequence words back into the page (merge_parts_pinned_kernel), where this thread polls them as it does
+  // find_one_kernel's.  Two launches, no copy, no stream synchronise (the batch path: a copy in, the tokeniser, the
+  // find, the merge, a copy out, a synchronise).  The delta image, a window or two, keeps find_one_kernel.
+  const uint32_t mid_ranges = (n_rows > O.few_max && n_rows <= O.mid_max)
+      ? latency_ranges(n_rows, limit, m->dev.n_windows, size_t(m->n_cus) * find_wgs_per_cu()) : 1u;
+  const bool mid = mid_ranges > 1;
+  if (mid) {
+    uint32_t* h_nb = reinterpret_cast<uint32_t*>(O.h_out + kMidNbAt);
+    uint32_t* h_start = reinterpret_cast<uint32_t*>(O.h_out + kMidStartAt);
+    uint64_t* h_off = reinterpret_cast<uint64_t*>(O.h_out + kMidOffAt);
+    for (uint32_t r = 0; r < n_rows; ++r) {
+      h_nb[r] = row_nb[r];
+      h_start[r] = m->dev.h_start_win[std::min<size_t>(len[row_of[r]], 255)];   // (tokenise_kernel: start_win[len])
+      h_off[r] = uint64_t(r) * 63;                        // a needle's codes start at qcodes + offsets[q] + q: [needle][64]
+    }
+    h_off[n_rows] = uint64_t(n_rows) * 63;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+  }
+  // more than kOneMaxNeedles rows, or latency mode: the codes travel in the pinned page (both images' launches read the first image's copy)
   const bool far = n_rows > kOneMaxNeedles;
-  if (far) {
+  if (far || mid) {
     std::memcpy(O.h_out + kOneCodesAt, codes, size_t(n_rows) * 64 * sizeof(uint16_t));
     std::memcpy(O.h_out + kOneTAt, T, size_t(n_rows) * sizeof(uint32_t));
     __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -1454,6 +1492,30 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     if (!m->d_phase) BLURRILY_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_phase), kPhaseBytes));
     if (which == 0) a.phase_clocks = m->d_phase;       // (trace build: find_one_kernel's wall-clock marks, 16 per workgroup)
 #endif
+    unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p) + which * part_bytes;
+    unsigned char* d_rows = O.d_out + which * kOneHostBytes;
+    if (mid && which == 0) {
+      const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
+      const uint32_t tasks = n_rows * mid_ranges;           // (<= 2 wgs: far below kOneMaxLists, whose keys and flags it borrows)
+      a.offsets = reinterpret_cast<const uint64_t*>(O.d_out + kMidOffAt);
+      a.qcodes = reinterpret_cast<const uint16_t*>(O.d_out + kOneCodesAt);
+      a.q_ntri = reinterpret_cast<const uint32_t*>(O.d_out + kOneTAt);
+      a.q_nb = reinterpret_cast<const uint32_t*>(O.d_out + kMidNbAt);
+      a.q_start = reinterpret_cast<const uint32_t*>(O.d_out + kMidStartAt);
+      a.nm_dense = std::max((m->nm_dense + 7u) & ~7u, ix.dense_min8);
+      a.nm_cmin = 0;                                        // (ranges leave nothing out of a step's count: measured, slower)
+      a.n_work = tasks; a.ranges = mid_ranges; a.short_only = 1;
+      a.part_keys = reinterpret_cast<unsigned long long*>(dp);
+      a.part_count = reinterpret_cast<uint32_t*>(dp + key_bytes);
+      a.queue = reinterpret_cast<uint32_t*>(dp + key_bytes + flag_bytes) + kMidMaxNeedles;   // (zero between launches: the merge hands it back)
+      a.pool_cap = find_pool_cap(limit);
+      if (launch_find(a, false, uint32_t(std::min<size_t>(tasks, wgs)), O.stream) < 0) return -1;
+      uint32_t merge_cap = 1024;
+      while (merge_cap < mid_ranges * limit) merge_cap <<= 1;
+      a.pool_cap = merge_cap;
+      return launch_merge_parts_pinned(a, n_rows, reinterpret_cast<trigram_match_t*>(d_rows),
+                                       reinterpret_cast<uint32_t*>(d_rows + kOneWordsAt), seq, O.stream);
+    }
     // one window per workgroup while that fills at most kOneMaxGrid of them, whole window pairs beyond; more than
     // eight needles: about a thousand workgroups in all -- two rounds of what the chip holds --, i.e. several
     // window pairs a workgroup (its later steps arrive with its own threshold: one_select's cheap way)
@@ -1467,8 +1529,6 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
     per = std::max(per, O.min_per);                       // (a test's way to the several-steps-per-workgroup path on a small image)
     const uint32_t grid = (ix.n_windows + per - 1) / per;
     if (size_t(grid) * n_rows > kOneMaxLists) { errno = EINVAL; return -1; }   // (cannot happen: grid <= kOneMaxGrid, far grids are small)
-    unsigned char* dp = static_cast<unsigned char*>(O.d_parts.p) + which * part_bytes;
-    unsigned char* d_rows = O.d_out + which * kOneHostBytes;
     return launch_find_one(a, codes, T, n_rows, per, grid, reinterpret_cast<unsigned long long*>(dp),
                            reinterpret_cast<uint32_t*>(dp + key_bytes), reinterpret_cast<trigram_match_t*>(d_rows),
                            reinterpret_cast<uint32_t*>(d_rows + kOneWordsAt), seq, O.stream, uint32_t(m->n_cus),
@@ -1659,7 +1719,7 @@ constexpr OptionSlot kMapOptions[] = {
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
     {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
     {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20},
-    {"retunes", 0, 0}, {"tune_inject", 0, 3}, {"mid_workgroups", 64, 1 << 16}, {"few_max", 1, kMidMaxNeedles}};
+    {"retunes", 0, 0}, {"tune_inject", 0, 3}, {"mid_workgroups", 64, 1 << 16}, {"few_max", 1, kMidMaxNeedles}, {"mid_max", 0, kMidMaxNeedles}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1710,6 +1770,7 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 25: m->tune_inject = int(value); return 0;      // (tests: the next measurement's bad sample)
     case 26: m->one.mid_workgroups = uint32_t(value); return 0;
     case 27: m->one.few_max = uint32_t(value); return 0;
+    case 28: m->one.mid_max = uint32_t(value); return 0;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1757,6 +1818,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 25: *value = m->tune_inject; return 0;
     case 26: *value = m->one.mid_workgroups; return 0;
     case 27: *value = m->one.few_max; return 0;
+    case 28: *value = m->one.mid_max; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -83,6 +83,7 @@ struct DeviceIndex {
   uint32_t* d_code_total     = nullptr;   // [kNumCodes]
   uint32_t* d_win_max_tri    = nullptr;   // [n_windows] most postings any one reference of the window has
   uint32_t* d_start_win      = nullptr;   // [256] window holding the first rank whose weight is >= the index
+  uint32_t  h_start_win[256] = {};        //       ... the host's copy (needles tokenised on the host: c_abi.hip, find_few)
   uint32_t* d_tomb           = nullptr;   // [(n_refs+31)/32] bit r: rank r was deleted after the build
   uint32_t  n_bitmaps        = 0;         // dense slices (each starts with its bitmap, inline in d_ent)
   uint32_t  dense_min8       = 0;         // a slice spanning at least this many entries is dense (a multiple of 8)

@@ -441,6 +441,7 @@ int device_index_build(const HostIndex& host, DeviceIndex* out, const IndexBuild
   ix.built_from = host.generation();
   ix.n_bitmaps = n_bitmaps;
   ix.dense_min8 = dense_min8;
+  std::copy(start_win.begin(), start_win.end(), ix.h_start_win);
   ix.mean_hit_slice = mean_hit_slice;
   ix.dense_share = dense_share;
   ix.ws_gain = ws_gain;
@@ -494,6 +495,7 @@ int device_index_clone(const DeviceIndex& src, int dst_device, DeviceIndex* out)
   copy(&ix.d_code_total, src.d_code_total, kNumCodes);
   copy(&ix.d_win_max_tri, src.d_win_max_tri, src.n_windows);
   copy(&ix.d_start_win, src.d_start_win, 256);
+  std::copy(src.h_start_win, src.h_start_win + 256, ix.h_start_win);
   copy(&ix.d_tomb, src.d_tomb, (size_t(src.n_refs) + 31) / 32 + 1);
   if (failed) {
     std::fprintf(stderr, "blurrily_hip: cloning the device image onto device %d failed\n", dst_device);

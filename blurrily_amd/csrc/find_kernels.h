@@ -142,6 +142,10 @@ int launch_normalise(const char* in, const uint64_t* offsets, uint32_t n, char* 
                      hipStream_t stream);
 int launch_find(const FindArgs& a, bool long_needles, uint32_t grid, hipStream_t stream);
 int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream);
+// ... the merged rows of needle q into host-coherent memory instead: rows[q][kOneMaxKeep], words[q] = {count, seq} (seq last,
+// behind a system-scope fence: the host polls it), and *a.queue back to zero.  a.keep <= kOneMaxKeep.
+int launch_merge_parts_pinned(const FindArgs& a, uint32_t n_items, trigram_match_t* rows, uint32_t* words, uint32_t seq,
+                              hipStream_t stream);
 // Small-haystack sweep over needles [0, a.n_work): four waves and one window's 4-bit counters per needle, four workgroups
 // per CU; needles with 16..64 distinct trigrams are appended to a.over_list.  keep <= kSmallMaxKeep, single pass.
 int launch_find_small(const FindArgs& a, uint32_t n_cus, hipStream_t stream);

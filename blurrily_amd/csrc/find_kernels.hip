@@ -272,6 +272,18 @@ int launch_merge_parts(const FindArgs& a, uint32_t n_items, hipStream_t stream) 
   return 0;
 }
 
+int launch_merge_parts_pinned(const FindArgs& a, uint32_t n_items, trigram_match_t* rows, uint32_t* words, uint32_t seq,
+                              hipStream_t stream) {
+  if (n_items == 0) return 0;
+  constexpr int NT = 1024;
+  static_assert(kOneMaxKeep <= NT, "a thread per row");
+  const size_t lds = size_t(a.pool_cap) * 8 + sizeof(Control) + 16;
+  hipLaunchKernelGGL((merge_parts_pinned_kernel<NT>), dim3(n_items), dim3(NT), lds, stream, a, rows, words, seq);
+  BLURRILY_HIP_TRY(hipGetLastError());
+  ::blurrily::note_launch("merge_parts_pinned_kernel");
+  return 0;
+}
+
 int launch_wsweep(const FindArgs& a, uint32_t w, uint32_t n, uint32_t n_cus, bool own_pass, hipStream_t stream) {
   if (n == 0) return 0;
   // needles per queue pop: whole 256-thread filters for big batches, smaller chunks when there are too

@@ -93,7 +93,8 @@ int blurrily_storage_delete(trigram_map haystack, uint32_t reference);
  * distinct trigrams at a limit of 1..120 (option "one_launch"; a second launch
  * over the delta image while puts are pending); otherwise one element of
  * blurrily_storage_find_batch -- which takes the same launch for up to "few_max"
- * (32; the kernel: up to 128) such needles, a row of the grid each. */
+ * (24; the kernel: up to 128) such needles, a row of the grid each, and still no
+ * copy for up to "mid_max" (128). */
 int blurrily_storage_find(trigram_map haystack, const char* needle,
                           uint16_t limit, trigram_match results);
 
@@ -155,8 +156,8 @@ int blurrily_normalize_batch_device(const char* d_packed, const uint64_t* d_offs
                                     char* d_out, uint32_t* d_non_ascii, void* stream);
 
 /* blurrily_storage_find_batch over un-normalised ASCII needles: normalised on the
- * device, then found (a handful -- up to "few_max" -- by the library on the host, byte
- * for byte the same, so that they share the single find's launch).  non_ascii (optional,
+ * device, then found (a handful -- up to "few_max" / "mid_max" -- by the library on the host, byte
+ * for byte the same, so that they share the single find's launch or its pinned page).  non_ascii (optional,
  * n slots) as above; rows of a flagged needle are those of its bytes >= 0x80 read as
  * non-letters. */
 int blurrily_storage_find_batch_raw(trigram_map haystack, const char* packed, const uint64_t* offsets,
@@ -294,10 +295,15 @@ size_t blurrily_storage_last_kernels(trigram_map haystack, char* out, size_t cap
  *   "one_launch"      (1)     blurrily_storage_find as ONE launch without copies where it can be (see there); 0: always the
  *                             batch's way.  "one_taken" (get): finds served that way so far.  "one_windows_per_wg" (0): at
  *                             least this many windows per workgroup of that launch (0: as few as 256 workgroups allow)
- *   "few_max"         (32)    blurrily_storage_find_batch / _raw: batches of up to this many needles (128 at most) share
+ *   "few_max"         (24)    blurrily_storage_find_batch / _raw: batches of up to this many needles (128 at most) share
  *                             the single find's launch, a row of the grid per needle; "mid_workgroups" (1024): the
  *                             workgroups such a launch aims at from nine needles on (a workgroup then takes several
  *                             window pairs)
+ *   "mid_max"         (128)   ... and batches of more than "few_max" and up to this many needles (128 at most; 0: none)
+ *                             are searched in latency mode without copies: tokenised on the host, the needle arrays
+ *                             read from a pinned page, the merged rows written back into it and polled there (two
+ *                             launches; larger batches, limits above 120 and needles of more than 64 distinct
+ *                             trigrams take the staged copies, the device's tokeniser and a stream synchronise)
  *   "host_chunk"      (131072) blurrily_storage_find_batch / _raw: a batch of at least twice as many needles goes
  *                             in chunks of this many through a three-stream pipeline (needles in, search, rows
  *                             out overlap); 0 = always one piece

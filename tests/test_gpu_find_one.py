@@ -196,6 +196,14 @@ def test_mutations_the_image_has_not_absorbed(geo):
     for i, nd in enumerate(needles[:16]):
         assert rows[i, :counts[i]].tolist() == o.find(nd, 10), nd
     m.set_option("one_windows_per_wg", 0)
+    # ... and a few dozen: the base image in latency mode over the pinned page (tombstones in its scans), the delta image by
+    # find_one_kernel, a needle's two lists merged on the host
+    pk, po = _pack(needles[:40])
+    for limit in (10, 64):
+        rows, counts = m.find_batch_packed(pk, po, limit)
+        assert "merge_parts_pinned_kernel" in m.last_kernels()
+        for i, nd in enumerate(needles[:40]):
+            assert rows[i, :counts[i]].tolist() == o.find(nd, limit), (nd, limit)
     # delete a pending put, put a deleted reference back: the log keeps up
     assert m.delete(200_001) == o.delete(200_001)
     back = sorted(victims)[0]
@@ -206,16 +214,17 @@ def test_mutations_the_image_has_not_absorbed(geo):
 
 
 def test_a_handful_of_needles_share_one_launch(geo):
-    """blurrily_storage_find_batch with up to "few_max" needles (32; the kernel takes up to 128): one launch, a row of the
+    """blurrily_storage_find_batch with up to "few_max" needles (24; the kernel takes up to 128): one launch, a row of the
     grid per needle (c_abi.hip: find_few) -- each element still exactly one blurrily_storage_find; needles without a
     posting take no row.  Up to sixteen needles travel as kernel arguments and the row's last workgroup merges; more are
-    read from the pinned page and the workgroup that finishes last merges (tickets).  A batch beyond few_max, or a limit
-    beyond 120, goes the old way."""
+    read from the pinned page and the workgroup that finishes last merges (tickets).  Beyond few_max and up to "mid_max"
+    (128) needles: latency mode's ranges with the needles read from the pinned page and the merged rows written back
+    into it (two launches, no copy); a limit beyond 120 goes the batch's way, copies and all."""
     m, chk, strings = geo
     rng = np.random.default_rng(8)
     few_max = m.get_option("few_max")
-    assert few_max == 32
-    for n, limit in [(2, 10), (5, 1), (16, 10), (16, 120), (9, 64), (17, 10), (32, 10), (24, 120), (33, 10), (3, 121)]:
+    assert few_max == 24
+    for n, limit in [(2, 10), (5, 1), (16, 10), (16, 120), (9, 64), (17, 10), (24, 10), (24, 120), (25, 10), (32, 10), (3, 121)]:
         picks = [strings[int(k)] for k in rng.integers(0, len(strings), size=n)]
         needles = [p[: max(1, len(p) - 1)] for p in picks]
         if n >= 5:
@@ -227,10 +236,47 @@ def test_a_handful_of_needles_share_one_launch(geo):
         went = m.get_option("one_taken") - taken
         for i, nd in enumerate(needles):
             assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (n, limit, nd)
-        if n <= few_max and limit <= 120:
-            assert went == sum(1 for nd in needles if chk.find(nd, 1))    # one row per needle that has any posting ...
+        rows_wanted = sum(1 for nd in needles if chk.find(nd, 1))
+        kernels = m.last_kernels()
+        if limit > 120:
+            assert went == 0 and not any("pinned" in k or "find_one" in k for k in kernels)   # the batch's way
+        elif rows_wanted <= few_max:
+            assert went == rows_wanted and kernels == ["find_one_kernel<1024>"]   # one row per needle that has any posting
         else:
-            assert went == 0                                   # ... and none when the batch goes the old way
+            assert went == rows_wanted and kernels == ["find_kernel<uint8_t,1024,true,true>", "merge_parts_pinned_kernel"]
+
+
+@pytest.mark.parametrize("n", [27, 32, 47, 64, 128])
+def test_a_servers_coalesced_finds_take_latency_mode_without_copies(geo, n):
+    """More than few_max and up to mid_max needles (defaults: 25 .. 128 needles with a posting): find_kernel<..., RANGED> over needle arrays in the
+    pinned page, merge_parts_pinned_kernel writing rows and sequence words back into it -- rows equal the live reference's
+    for every needle, at two limits, twice in a row (the queue word returns to zero), empty needles and needles without a
+    posting among them; with mid_max 0 the same batch goes the batch's way and says the same."""
+    m, chk, strings = geo
+    rng = np.random.default_rng(180 + n)
+    assert m.get_option("mid_max") == 128
+    for limit in (10, 100):
+        for rep in range(2):
+            picks = [strings[int(k)] for k in rng.integers(0, len(strings), size=n)]
+            needles = [p[: max(1, len(p) - 1)] if k % 3 else p for k, p in enumerate(picks)]
+            needles[2] = b""
+            needles[5] = b"qqqqzzzzxxxx"
+            needles[7] = b" ".join(picks[7:10])[:60]             # (over 15 trigrams: byte counters beyond nib_windows)
+            packed, off = _pack(needles)
+            taken = m.get_option("one_taken")
+            rows, counts = m.find_batch_packed(packed, off, limit)
+            assert m.get_option("one_taken") - taken == sum(1 for nd in needles if chk.find(nd, 1))
+            assert m.last_kernels() == ["find_kernel<uint8_t,1024,true,true>", "merge_parts_pinned_kernel"]
+            for i, nd in enumerate(needles):
+                assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (n, limit, nd)
+    m.set_option("mid_max", 0)
+    try:
+        taken = m.get_option("one_taken")
+        rows2, counts2 = m.find_batch_packed(packed, off, 100)
+        assert m.get_option("one_taken") == taken and "merge_parts_pinned_kernel" not in m.last_kernels()
+        assert np.array_equal(counts2, counts) and all(np.array_equal(rows2[i, :counts[i]], rows[i, :counts[i]]) for i in range(n))
+    finally:
+        m.set_option("mid_max", 128)
 
 
 @pytest.mark.parametrize("n", [17, 32, 64, 128])
@@ -255,5 +301,5 @@ def test_a_servers_coalesced_finds_share_one_launch(geo, n):
                 for i, nd in enumerate(needles):
                     assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (n, limit, wgs, nd)
     finally:
-        m.set_option("few_max", 32)
+        m.set_option("few_max", 24)
         m.set_option("mid_workgroups", 1024)

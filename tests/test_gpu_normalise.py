@@ -156,7 +156,7 @@ def test_a_handful_of_raw_needles_is_normalised_on_the_host_and_shares_one_launc
     raw += [b"", b"  ", b"!!!", b"Two\nLines", b"a\x00b", b"\x00", b"x  y", b"caf\xc3\xa9"]
     big_p, big_o = _pack(raw)
     want_rows, want_counts, want_flags = m.find_batch_raw_packed(big_p, big_o, 10)       # (408 needles: the device normalises)
-    assert m.get_option("few_max") == 32
+    assert m.get_option("few_max") == 24
     taken = m.get_option("one_taken")
     for lo in range(0, len(raw), 17):                                                  # batches of 17 (and a shorter last one)
         part = raw[lo:lo + 17]
@@ -166,6 +166,13 @@ def test_a_handful_of_raw_needles_is_normalised_on_the_host_and_shares_one_launc
         for i in range(len(part)):
             assert np.array_equal(rows[i, :counts[i]], want_rows[lo + i, :counts[i]]), part[i]
     assert m.get_option("one_taken") > taken                                           # ... through the shared launch
+    for lo in range(0, len(raw), 61):                                                  # batches of 61 (beyond few_max: the pinned page still, one window here: find_one_kernel's rows)
+        part = raw[lo:lo + 61]
+        p_, o_ = _pack(part)
+        rows, counts, flags = m.find_batch_raw_packed(p_, o_, 10)
+        assert np.array_equal(counts, want_counts[lo:lo + len(part)]) and np.array_equal(flags, want_flags[lo:lo + len(part)])
+        for i in range(len(part)):
+            assert np.array_equal(rows[i, :counts[i]], want_rows[lo + i, :counts[i]]), part[i]
     # and the single raw needle
     for i in (0, 5, len(raw) - 5, len(raw) - 1):
         p_, o_ = _pack([raw[i]])

@@ -34,7 +34,7 @@ def main():
         hay, off = W.geonames(n, max(1000, int(500000 * min(1.0, scale * 4))), 3)
     m = RawMap()
     m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32))
-    for key in ("nm_cmin", "nm_dense", "wsweep", "nm_min_windows", "ws_autotune"):                 # e.g. NM_CMIN=0: nothing left out of the needle-major count
+    for key in ("nm_cmin", "nm_dense", "wsweep", "nm_min_windows", "ws_autotune", "few_max"):                 # e.g. NM_CMIN=0: nothing left out of the needle-major count
         if os.environ.get(key.upper()):
             try:
                 m.set_option(key, int(os.environ[key.upper()]))
@@ -45,7 +45,7 @@ def main():
     lib = _native.lib()
     lib.blurrily_debug_phase_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     m.set_stats(True)
-    for batch in (512, nq):
+    for batch in ([int(x) for x in os.environ['PH_BATCHES'].split()] if os.environ.get('PH_BATCHES') else (512, nq)):
         qp, qo = W.queries(hay, off, batch, 3000)
         t = time.perf_counter()
         rows, counts = m.find_batch_packed(qp, qo, 10)
