@@ -10,7 +10,7 @@ from blurrily_amd import RawMap, _native
 hay, off = W.bench_haystack("geonames", 1.0)
 n = len(off) - 1
 m = RawMap(); m.put_many_packed(hay, off, np.arange(1, n + 1, dtype=np.uint32)); m.sync_device()
-m.set_option("few_max", 1)
+m.set_option("few_max", 1); m.set_option("mid_max", 0)
 lib = _native.lib(); lib.blurrily_debug_phase_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 for batch in [int(x) for x in os.environ.get("MID_N", "32 128").split()]:
     acc = []
@@ -25,6 +25,18 @@ for batch in [int(x) for x in os.environ.get("MID_N", "32 128").split()]:
         us = (t - t[:, 0].min()) / 100.0
         us[t == 0] = np.nan
         learned = ~np.isnan(us[:, 2])
+        if rep == 7 and os.environ.get("LAT_DUMP"):
+            dur = us[:, 4] - us[:, 0]
+            info = buf.reshape(8192, 16)[:, 5][buf.reshape(8192, 16)[:, 0] != 0]
+            order = np.argsort(-dur)[:24]
+            print("  slowest tasks: us (learn, range) | T range own w0 w1 qs")
+            for k in order:
+                v = int(info[k])
+                print(f"    {dur[k]:6.1f} ({(us[k, 2] - us[k, 1]) if learned[k] else 0:5.1f}, {us[k, 3] - (us[k, 2] if learned[k] else us[k, 1]):5.1f}) | T {v & 0xFF:3d} r {(v >> 8) & 0xFFF:3d} own {(v >> 20) & 1} w [{(v >> 24) & 0xFFF}, {(v >> 36) & 0xFFF}) qs {(v >> 48) & 0xFFF}")
+            Tt = np.array([int(x) & 0xFF for x in info]); own = np.array([(int(x) >> 20) & 1 for x in info]); w0s = np.array([(int(x) >> 24) & 0xFFF for x in info])
+            rng_t = us[:, 3] - np.where(learned, us[:, 2], us[:, 1])
+            for name, sel in (("T<=15", Tt <= 15), ("T>15 nib part", (Tt > 15) & (w0s < 64)), ("T>15 byte part", (Tt > 15) & (w0s >= 64)), ("own range", own == 1)):
+                if sel.any(): print(f"  {name}: {sel.sum()} tasks, range sweep median {np.median(rng_t[sel]):.1f} p90 {np.percentile(rng_t[sel], 90):.1f} max {rng_t[sel].max():.1f}")
         acc.append([len(t), np.median(us[:, 0]), us[:, 0].max(), np.median(us[:, 1] - us[:, 0]),
                     np.median(us[learned, 2] - us[learned, 1]) if learned.any() else 0.0, learned.mean(),
                     np.median(us[:, 3] - np.where(learned, us[:, 2], us[:, 1])), np.nanmax(us[:, 3] - np.where(learned, us[:, 2], us[:, 1])),
