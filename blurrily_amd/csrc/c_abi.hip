@@ -156,6 +156,7 @@ struct trigram_map_t {
   float       ws_tuned_ms[8][3] = {};   // what the measurement saw (needle-major, window-major, slices left out)
   int         last_tuned = -1;          // the class measured most recently ("tuned_*_us" report its figures)
   int         last_sweep = 0;           // which sweep the last large batch of short needles took (1 / 2 / 3; 0: none yet)
+  uint32_t latency_tasks = 0;           // option "latency_tasks": tasks latency mode aims at per resident workgroup (0: latency_ranges' rule)
   std::string last_kernels;             // the find kernels the last batch on the base image launched, '+'-joined (blurrily_storage_last_kernels)
   size_t      class_hint = 0;           // a chunked host batch: the WHOLE batch's size decides the class, not the chunk's
   hipEvent_t  tune_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -329,15 +330,18 @@ constexpr size_t kStageBytes = 1 << 20;   // pinned staging per direction for sm
 
 // the timed build of the kernels, or (while request counters are collected) the counted one
 // Latency mode: the ranges a needle's windows are cut into when n needles are too few to fill `wgs` resident workgroups
-// (1: whole needles).  Tasks aimed at: ONE per workgroup up to about fifty needles -- every task starts at once, none
-// queues behind another's learning sweep --, two beyond (round 6, tools/experiments/r6_run_lt.sh, host clock at Geonames
-// scale, one / two / four tasks per workgroup: 32 needles 146 / 168 / 223 us, 48: 197 / 226 / 282, 64: 230 / 226 / 275,
-// 128: 324 / 275 / 306; through round 5 two, and four from a hundred needles on); from about one needle per FOUR
-// workgroups whole needles win (through round 4: per workgroup -- the whole-needle sweeps have become faster since, the
-// ranged one pays its learning sweep and merge: at Geonames scale 256 needles 503 -> 366 us, 512: 737 -> 617).
-uint32_t latency_ranges(size_t n, uint32_t limit, uint32_t n_windows, size_t wgs) {
-  if (limit == 0 || limit > 1024 || n * 4 > wgs || n_windows <= 2) return 1;
-  const size_t target_tasks = (n < 56 ? 1 : 2) * wgs;
+// (1: whole needles).  Tasks aimed at: ONE per workgroup up to sixty needles -- every task starts at once, none
+// queues behind another's learning sweep --, two beyond (round 6, tools/experiments/r6_run_mid5.sh, host clock at Geonames
+// scale, one / two / three / four tasks per workgroup: 32 needles 131 / 179 / 197 / 228 us, 56: 188 / 226 / 244 / 268,
+// 64: 216 / 209 / 239 / 274, 128: 319 / 261 / 285 / 302; through round 5 two, and four from a hundred needles on); from
+// seven needles per SIXTEEN workgroups on (225 needles on this chip) whole needles win: up to a needle per workgroup their
+// time is the slowest needle's, 368 us at Geonames scale whatever the batch, and ranges take 243 us at 129 needles, 298 at
+// 160, 310 at 192, 356 at 224, 385 at 256 (round 6: tools/experiments/r6_lat256.py; through round 5 the crossover sat at one
+// needle per four workgroups, through round 4 at one per workgroup: the ranged sweep paid a whole learning sweep per task
+// and ended with its dearest tasks).
+uint32_t latency_ranges(size_t n, uint32_t limit, uint32_t n_windows, size_t wgs, uint32_t tasks_per_wg) {
+  if (limit == 0 || limit > 1024 || n * 16 > wgs * 7 || n_windows <= 2) return 1;
+  const size_t target_tasks = (tasks_per_wg ? tasks_per_wg : n <= 60 ? 1 : 2) * wgs;      // (option "latency_tasks": 0 = this rule)
   uint32_t ranges = uint32_t(std::min<size_t>((n_windows + 1) / 2, target_tasks / n));   // ranges are whole window pairs
   return std::max<uint32_t>(1u, std::min<uint32_t>(ranges, std::max<uint32_t>(1u, 4096u / limit)));      // (the merge's pool)
 }
@@ -429,7 +433,7 @@ int run_find_on(trigram_map m, const DeviceIndex& ix, const uint32_t* d_code_tot
     // Latency mode: a batch too small to fill the GPU cuts every needle's windows into ranges
     // swept by different workgroups, then merges the per-range candidates (single pass only).
     const size_t wgs = size_t(m->n_cus) * find_wgs_per_cu();
-    const uint32_t ranges = latency_ranges(n, limit, ix.n_windows, wgs);
+    const uint32_t ranges = latency_ranges(n, limit, ix.n_windows, wgs, m->latency_tasks);
     if (ranges > 1) {
       const size_t tasks = n * ranges;
       const size_t key_bytes = align_up(tasks * limit * 8, 256);
@@ -1424,6 +1428,7 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   auto& O = m->one;
   NameScope name_scope(&m->last_kernels);                 // (the launches below note their kernels' names in the map)
   m->last_kernels.clear();
+  m->last_sweep = 0;                                      // (no sweep of a class of batches: a single launch, or latency mode)
   if (!O.h_out) {
     // stream, pinned page and its device address: built in locals and kept only when ALL of them exist (a half-made set
     // -- a stream without its page -- would have the next find skip this block and poll a null page)
@@ -1458,7 +1463,7 @@ static int find_few(trigram_map m, const char* const* s, const size_t* len, size
   // find_one_kernel's.  Two launches, no copy, no stream synchronise (the batch path: a copy in, the tokeniser, the
   // find, the merge, a copy out, a synchronise).  The delta image, a window or two, keeps find_one_kernel.
   const uint32_t mid_ranges = (n_rows > O.few_max && n_rows <= O.mid_max)
-      ? latency_ranges(n_rows, limit, m->dev.n_windows, size_t(m->n_cus) * find_wgs_per_cu()) : 1u;
+      ? latency_ranges(n_rows, limit, m->dev.n_windows, size_t(m->n_cus) * find_wgs_per_cu(), m->latency_tasks) : 1u;
   const bool mid = mid_ranges > 1;
   if (mid) {
     uint32_t* h_nb = reinterpret_cast<uint32_t*>(O.h_out + kMidNbAt);
@@ -1719,7 +1724,8 @@ constexpr OptionSlot kMapOptions[] = {
     {"nm_min_windows", 0, 1 << 20}, {"tuned_class", 0, 0}, {"tuned_nm_us", 0, 0}, {"tuned_ws_us", 0, 0},
     {"tuned_leave_us", 0, 0}, {"small_sweep", 0, 1}, {"small_min_needles", 0, 1ll << 32},
     {"one_launch", 0, 1}, {"one_taken", 0, 0}, {"one_windows_per_wg", 0, 1 << 20},
-    {"retunes", 0, 0}, {"tune_inject", 0, 3}, {"mid_workgroups", 64, 1 << 16}, {"few_max", 1, kMidMaxNeedles}, {"mid_max", 0, kMidMaxNeedles}};
+    {"retunes", 0, 0}, {"tune_inject", 0, 3}, {"mid_workgroups", 64, 1 << 16}, {"few_max", 1, kMidMaxNeedles}, {"mid_max", 0, kMidMaxNeedles},
+    {"latency_tasks", 0, 16}};
 constexpr OptionSlot kProcessOptions[] = {{"host_threads", 0, 256}, {"build_trace", 0, 1}};
 int find_option(const OptionSlot* tab, size_t n, const char* key) {
   for (size_t i = 0; i < n; ++i) if (std::strcmp(tab[i].key, key) == 0) return int(i);
@@ -1771,6 +1777,7 @@ int blurrily_storage_set_option(trigram_map m, const char* key, long long value)
     case 26: m->one.mid_workgroups = uint32_t(value); return 0;
     case 27: m->one.few_max = uint32_t(value); return 0;
     case 28: m->one.mid_max = uint32_t(value); return 0;
+    case 29: m->latency_tasks = uint32_t(value); return 0;
   }
   if (i != 6) std::fill(std::begin(m->ws_choice), std::end(m->ws_choice), 0);   // the sweep's choice is measured again
   return 0;
@@ -1819,6 +1826,7 @@ int blurrily_storage_get_option(trigram_map m, const char* key, long long* value
     case 26: *value = m->one.mid_workgroups; return 0;
     case 27: *value = m->one.few_max; return 0;
     case 28: *value = m->one.mid_max; return 0;
+    case 29: *value = m->latency_tasks; return 0;
     default: errno = EINVAL; return -1;
   }
 }

@@ -304,6 +304,9 @@ size_t blurrily_storage_last_kernels(trigram_map haystack, char* out, size_t cap
  *                             read from a pinned page, the merged rows written back into it and polled there (two
  *                             launches; larger batches, limits above 120 and needles of more than 64 distinct
  *                             trigrams take the staged copies, the device's tokeniser and a stream synchronise)
+ *   "latency_tasks"   (0)     latency mode (batches too small to give every resident workgroup a needle): the tasks a
+ *                             needle's windows are cut into, aimed at per resident workgroup; 0: one up to 60 needles,
+ *                             two beyond (measured at Geonames scale)
  *   "host_chunk"      (131072) blurrily_storage_find_batch / _raw: a batch of at least twice as many needles goes
  *                             in chunks of this many through a three-stream pipeline (needles in, search, rows
  *                             out overlap); 0 = always one piece

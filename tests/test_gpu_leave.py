@@ -107,9 +107,14 @@ def test_single_words_small_windows_and_latency_mode_is_left_alone():
     # settled candidates' tail (from 150 on) neither; limit 100 does (the 1 024-entry pool, a tail of 256)
     q2, qo2 = W.queries(hay, off, 40, 57)
     rows, counts = m.find_batch_packed(q2, qo2, 10)
-    assert m.get_option("last_sweep") == 0
+    assert m.last_kernels() == ["find_kernel<uint8_t,1024,true,true>", "merge_parts_pinned_kernel"]   # (over the pinned page: c_abi.hip, find_few)
     want = o.batch(q2, qo2, limit=10)
     assert np.array_equal(counts, want["counts"])
+    m.set_option("mid_max", 0)                                  # ... and the batch's way, copies and all
+    rows, counts = m.find_batch_packed(q2, qo2, 10)
+    assert m.get_option("last_sweep") == 0 and m.last_kernels() == ["find_kernel<uint8_t,1024,true,true>"]
+    assert np.array_equal(counts, want["counts"])
+    m.set_option("mid_max", 128)
     _check(m, o, q[:int(qo[4000])], qo[:4001], 100, expect_left_out=False)   # (the hundredth-best match of a word is a poor one: little to leave out)
     assert m.get_option("last_sweep") == 3
     rows, counts = m.find_batch_packed(q, qo, 200)

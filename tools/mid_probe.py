@@ -17,6 +17,9 @@ reps = int(os.environ.get("MID_REPS", "40"))
 for batch in [int(x) for x in os.environ.get("MID_N", "8 16 17 32 64 128 256").split()]:
     t = []
     sets = [W.queries(hay, off, batch, 100 + rep) for rep in range(reps + 3)]      # (generated ahead: the calls follow each other)
+    if os.environ.get("MID_FIXED"):                                                 # bench.py's way: the step batch's first needles, again and again
+        bq, bo = W.bench_needles(hay, off, os.environ.get("MID_WORKLOAD", "geonames"), 1.0, 0, 1)
+        sets = [(bq, np.ascontiguousarray(bo[:batch + 1]))] * (reps + 3)
     for rep in range(reps + 3):
         q, qo = sets[rep]
         t0 = time.perf_counter(); rows, counts = m.find_batch_packed(q, qo, limit); dt = time.perf_counter() - t0
