@@ -489,6 +489,16 @@ def test_randomised_configurations(seed):
         assert m.delete(r) == o.delete(r)
     m.put(b"an entirely new entry", 2**31 - 1, 0); o.put(b"an entirely new entry", 2**31 - 1, 0)
     _check_batch(m, o, needles[:20] + [b"an entirely new"], limit)
+    k = int(rng.integers(25, 225))                             # latency mode under mutation: tombstones in its scans, the delta image beside it
+    some = (needles * 2)[:k]                                   # (up to 128 needles over the pinned page, beyond by the batch's copies)
+    packed = b"".join(some)
+    offs = np.zeros(len(some) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in some])
+    rows, counts = m.find_batch_packed(packed, offs, limit)
+    for i, nd in enumerate(some[:len(needles)]):
+        assert rows[i, :counts[i]].tolist() == o.find(nd, limit), (nd, limit, k)
+    for i in range(len(needles), k):                           # (the second copy of a needle says what the first says)
+        assert rows[i, :counts[i]].tolist() == rows[i - len(needles), :counts[i - len(needles)]].tolist()
     big = needles * 10                                         # > 1000 needles: whole needles per workgroup
     packed = b"".join(big)
     offs = np.zeros(len(big) + 1, dtype=np.uint64)
