@@ -279,6 +279,61 @@ def test_a_servers_coalesced_finds_take_latency_mode_without_copies(geo, n):
         m.set_option("mid_max", 128)
 
 
+def test_latency_mode_over_the_pinned_page_at_its_edges(geo):
+    """The corners of find_few's latency-mode half: two needles cut into as many ranges as there are window pairs ("few_max" 1),
+    sixteen tasks aimed at per workgroup, limits 1 and 120, exactly 25 and exactly 128 needles with postings, a batch of nothing
+    but needles without a posting (no launch at all), a needle of more than 64 distinct trigrams in the batch (the whole batch
+    goes the batch's way) and one of exactly the most the launch takes -- every row against the live reference."""
+    m, chk, strings = geo
+    rng = np.random.default_rng(91)
+    pick = lambda k: [strings[int(i)] for i in rng.integers(0, len(strings), size=k)]
+
+    def check(needles, limit, pinned):
+        packed, off = _pack(needles)
+        rows, counts = m.find_batch_packed(packed, off, limit)
+        if pinned is not None:
+            assert ("merge_parts_pinned_kernel" in m.last_kernels()) == pinned, (len(needles), limit, m.last_kernels())
+        for i, nd in enumerate(needles):
+            assert rows[i, :counts[i]].tolist() == chk.find(nd, limit), (len(needles), limit, nd)
+
+    try:
+        m.set_option("few_max", 1)
+        for limit in (1, 10, 120):
+            check(pick(2), limit, True)                        # two needles, a range per window pair
+        m.set_option("latency_tasks", 16)
+        check(pick(40), 10, True)
+        m.set_option("latency_tasks", 0)
+        m.set_option("few_max", 24)
+        check(pick(25), 1, True)
+        check(pick(25), 120, True)
+        check(pick(128), 10, True)
+        taken = m.get_option("one_taken")
+        check([b""] * 30, 10, None)                            # nothing to search for: no launch
+        assert m.get_option("one_taken") == taken
+        long_one = b" ".join(pick(8))[:120]                    # (well over 64 distinct trigrams)
+        assert len(set(Oracle.tokenise(long_one))) > 64
+        check(pick(29) + [long_one], 10, False)
+        # (a needle of more than 64 distinct trigrams where ranges are taken -- alone, or among a few dozen: the ranged launch
+        # leaves it to the launches behind it.  Through round 6 that launch never came back: needle_major.inc, find_kernel)
+        grow = b" ".join(pick(30))
+        for want in (65, 100, 127, 128, 140):
+            nd = next(grow[:k] for k in range(30, 400) if len(set(Oracle.tokenise(grow[:k]))) >= want)
+            check([nd], 10, False)
+            assert _find(m, nd, 10) == chk.find(nd, 10)
+            check(pick(3) + [nd] + pick(2), 10, False)
+        base = b" ".join(pick(8))
+        full = max((base[:k] for k in range(40, 110) if len(set(Oracle.tokenise(base[:k]))) <= 64), key=len)
+        assert len(set(Oracle.tokenise(full))) >= 56           # (as many distinct trigrams as the launch takes, or nearly)
+        check(pick(29) + [full], 10, True)
+        m.set_option("mid_max", 10)                            # (below few_max: the shared launch still takes up to few_max)
+        check(pick(20), 10, False)
+        assert m.last_kernels() == ["find_one_kernel<1024>"]
+        check(pick(30), 10, False)                             # ... and beyond it the batch's way
+    finally:
+        for key, value in (("few_max", 24), ("mid_max", 128), ("latency_tasks", 0)):
+            m.set_option(key, value)
+
+
 @pytest.mark.parametrize("n", [17, 32, 64, 128])
 def test_a_servers_coalesced_finds_share_one_launch(geo, n):
     """The same launch for up to 128 needles (option "few_max" raised to the kernel's limit): codes from the pinned page, a
