@@ -483,12 +483,15 @@ def test_randomised_configurations(seed):
         assert m.delete(r) == o.delete(r)
     q, qo = W.queries(hay, off, 110, seed=80 + seed)
     needles = W.unpack(q, qo) + [b"", b"q", strings[0] + b" " + strings[-1] + b" " + strings[n // 2]]
+    # (needles of more than 64 and of more than 127 distinct trigrams: the byte-counter and the 16-bit launches behind the
+    # first one -- in the small batches below as well, where round 6 found the ranged launch waiting for ever)
+    needles += [b" ".join(strings[(7 * k + seed) % n] for k in range(12))[:120], b" ".join(strings[(11 * k + seed) % n] for k in range(30))[:250]]
     limit = int(rng.choice([1, 2, 10, 33, 100, 257]))
     _check_batch(m, o, needles, limit)
     for r in rng.choice(refs, size=min(50, n // 8), replace=False).tolist():     # and after (tombstones)
         assert m.delete(r) == o.delete(r)
     m.put(b"an entirely new entry", 2**31 - 1, 0); o.put(b"an entirely new entry", 2**31 - 1, 0)
-    _check_batch(m, o, needles[:20] + [b"an entirely new"], limit)
+    _check_batch(m, o, needles[:20] + needles[-2:] + [b"an entirely new"], limit)
     k = int(rng.integers(25, 225))                             # latency mode under mutation: tombstones in its scans, the delta image beside it
     some = (needles * 2)[:k]                                   # (up to 128 needles over the pinned page, beyond by the batch's copies)
     packed = b"".join(some)
