@@ -31,11 +31,12 @@ long70 = b" ".join(strings[7 * k] for k in range(14))[:110]
 long200 = b" ".join(strings[11 * k] for k in range(40))[:250]
 mid20 = b" ".join(strings[5 * k] for k in range(4))[:40]
 print(len(set(Oracle.tokenise(long70))), len(set(Oracle.tokenise(long200))), len(set(Oracle.tokenise(mid20))), flush=True)
-for forced in ((), (("wsweep", 1), ("ws_min_needles", 0), ("ws_min_windows", 0), ("ws_min_slice", 0), ("ws_autotune", 0))):
+for forced in ((), (("wsweep", 1), ("ws_min_needles", 0), ("ws_min_windows", 0), ("ws_min_slice", 0), ("ws_static_slice", 0), ("ws_autotune", 0), ("small_sweep", 0))):
     for k, v in forced: m.set_option(k, v)
     for size in (20000, 5000):
         run(f"{forced and 'ws forced, ' or ''}nothing to find", (nothing * size)[:size])
         run(f"{forced and 'ws forced, ' or ''}65..127 trigrams only", [long70] * size)
         run(f"{forced and 'ws forced, ' or ''}more than 127 only", [long200] * (size // 10))
         run(f"{forced and 'ws forced, ' or ''}16..64 trigrams only", [mid20] * size)
+        if forced: run("ws forced, a mix that is mostly nothing", ((nothing * 5 + [mid20, strings[3], long70]) * size)[:size])
 print("all done")
